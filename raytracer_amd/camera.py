@@ -1,0 +1,2 @@
+"""Reference-compatible module name; the class lives in raytracer_amd.scene."""
+from .scene import Camera  # noqa: F401
