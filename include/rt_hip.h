@@ -1,0 +1,144 @@
+/*
+ * rt_hip.h — C-ABI of librt_hip.so, the MI355X (gfx950) renderer for the `render_vectorized()`
+ * hot path of AviadDahan/raytracer.
+ *
+ * The reference is pure Python/NumPy and has no FFI; each entry point below names the reference
+ * function (file:line under the reference checkout) whose work it replaces.  The Python host code
+ * (raytracer_amd/_lib.py) binds exactly these symbols with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain C, no C++/torch types.  Every function returns an rt_status (0 = OK, < 0 =
+ * error) and never throws or aborts; rt_last_error() returns a thread-local message for the last
+ * failure on the calling thread.  All input arrays stay owned by the caller and are copied.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,        /* bad argument (null pointer, negative size, unknown enum, ...) */
+  RT_ERR_HIP = -2,            /* a HIP runtime call failed; message has hipGetErrorString */
+  RT_ERR_NOMEM = -3,          /* device or host allocation failed */
+  RT_ERR_QUEUE_OVERFLOW = -4, /* a bounce queue overflowed: render fewer rows per call (row sets) */
+  RT_ERR_NO_DEVICE = -5
+} rt_status;
+
+typedef enum rt_surface_type { RT_SPHERE = 0, RT_PLANE = 1, RT_BOX = 2 } rt_surface_type;
+typedef enum rt_precision {
+  RT_FP64 = 0, /* every operation in IEEE double, evaluation order of the reference */
+  RT_FP32 = 1  /* fast mode: nearest-hit geometry in fp64, shadow/shading arithmetic in fp32 */
+} rt_precision;
+typedef enum rt_jitter_mode {
+  RT_JITTER_PIXEL_KEYED = 0, /* u = hash(seed, pixel, depth, light, cell): pixels independent */
+  RT_JITTER_NUMPY_STREAM = 1 /* the MT19937 stream np.random.seed(seed) would feed the reference */
+} rt_jitter_mode;
+typedef enum rt_out_format { RT_OUT_F64 = 0, RT_OUT_F32 = 1, RT_OUT_U8 = 2 } rt_out_format;
+enum { RT_FLAG_ASYNC = 1,  /* device output only: return after enqueueing; call rt_sync() */
+       RT_FLAG_TIMING = 2  /* bracket every kernel with HIP events, fill the *_ms stats fields */ };
+
+/*
+ * Scene description, in scene-file (list) order — the order defines nearest-hit tie-breaking
+ * (reference ray_tracer.py:119-125).  Mirrors the objects the reference's renderer reads:
+ * surfaces (surfaces/sphere.py:5-8, infinite_plane.py:5-9, cube.py:5-12), the materials_array dict
+ * (ray_tracer.py:454-460), Light (light.py:4-10), SceneSettings.background_color.
+ */
+typedef struct rt_scene_desc {
+  int32_t n_surfaces;
+  const int32_t* surf_type;     /* [n] rt_surface_type */
+  const double* surf_data;      /* [n][8] sphere: cx cy cz r | plane: nx ny nz offset (n unit) | box: min xyz, max xyz */
+  const int32_t* surf_material; /* [n] 0-based material index */
+  int32_t n_materials;
+  const double* materials;      /* [m][11] diffuse rgb, specular rgb, reflection rgb, shininess, transparency */
+  int32_t n_lights;
+  const double* lights;         /* [l][9] position xyz, color rgb, specular_intensity, shadow_intensity, radius */
+  double background[3];
+} rt_scene_desc;
+
+/* Camera after Camera.setup() (reference camera.py:17-28). */
+typedef struct rt_camera {
+  double pos[3], forward[3], right[3], up[3];
+  double screen_distance, screen_width, screen_height;
+} rt_camera;
+
+/*
+ * One render call = the rows of a row set of one frame.  Row set: rows y in [0,height) with
+ * ((y / block_rows) % n_parts) == part; n_parts <= 1 selects every row.  The output holds the
+ * set's rows in ascending y, width*3 values each (the multi-GPU path renders one part per rank).
+ */
+typedef struct rt_frame {
+  int32_t width, height;
+  int32_t block_rows, part, n_parts;
+  int32_t n_shadow;     /* SceneSettings.root_number_shadow_rays */
+  int32_t max_depth;    /* SceneSettings.max_recursions */
+  int32_t precision;    /* rt_precision */
+  int32_t jitter_mode;  /* rt_jitter_mode */
+  uint32_t jitter_seed;
+  int32_t out_format;   /* rt_out_format; U8 = clip/x255/truncate of reference save_image, ray_tracer.py:606-608 */
+  int32_t flags;        /* RT_FLAG_* */
+} rt_frame;
+
+#define RT_MAX_LEVELS 32
+typedef struct rt_stats {
+  int64_t rays;         /* R: radiance rays traced (reference's "total rays", ray_tracer.py:486,602) */
+  int64_t hits;
+  int64_t shadow_rays;  /* Sh = hits x lights x max(n,1)^2 */
+  int64_t segments;     /* extra shadow-walk queries beyond the first per shadow ray (fp64 mode; -1 in fp32 mode) */
+  int32_t batches;      /* non-empty levels (pixel-keyed) or DFS batches (numpy stream) */
+  int32_t levels;
+  int64_t level_rays[RT_MAX_LEVELS];
+  int64_t level_hits[RT_MAX_LEVELS];
+  float trace_ms, shade_ms, other_ms;   /* RT_FLAG_TIMING: summed kernel durations (HIP events) */
+  int32_t trace_launches, shade_launches;
+  float total_ms;                        /* RT_FLAG_TIMING: first kernel start -> last kernel end */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+const char* rt_last_error(void);
+int rt_device_count(int* count);
+
+/* Pack + upload a scene to `device` (type-sorted device records, original index kept).  Replaces
+ * the per-call object walking of render_vectorized (ray_tracer.py:454-460, 518). */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Use an external HIP stream (a hipStream_t, e.g. torch's current stream) for every later call on
+ * this scene; NULL restores the scene's own stream. */
+int rt_scene_set_stream(rt_scene* scene, void* hip_stream);
+int rt_sync(rt_scene* scene);
+
+/* Number of rows in a row set (host arithmetic only). */
+int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part, int32_t n_parts, int32_t* rows);
+
+/*
+ * Render a row set.  Replaces render_vectorized (ray_tracer.py:437-604) including
+ * Camera.generate_all_rays / generate_rays_for_rows (camera.py:46-104).
+ * `out`: rows*width*3 elements of out_format, host memory (out_is_device = 0; the call blocks) or
+ * device memory on the scene's device (out_is_device = 1; blocks unless RT_FLAG_ASYNC).
+ * `stats` may be NULL; with RT_FLAG_ASYNC it is filled by the next rt_sync() on this scene
+ * (the pointer must stay valid until then).
+ */
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, void* out, int out_is_device,
+              rt_stats* stats);
+
+/* Test/utility exports (host pointers, fp64), one per reference helper:
+ * rt_nearest_hit          == find_nearest_intersection_batch (ray_tracer.py:112-127)
+ * rt_shadow_transmission  == compute_shadow_transmission_batch (ray_tracer.py:247-293)
+ * rt_camera_rays          == Camera.generate_rays_for_rows (camera.py:75-104) */
+int rt_nearest_hit(rt_scene* scene, const double* origins, const double* dirs, int64_t n_rays,
+                   double* t_out, int32_t* idx_out, double* normals_out);
+int rt_shadow_transmission(rt_scene* scene, const double* origins, const double* dirs, const double* max_dist,
+                           int64_t n_rays, double* out);
+int rt_camera_rays(rt_scene* scene, const rt_camera* camera, int32_t width, int32_t height, int32_t y0, int32_t y1,
+                   double* origins_out, double* dirs_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

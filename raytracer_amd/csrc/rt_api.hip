@@ -1,0 +1,476 @@
+// rt_api.hip — host side of librt_hip.so: the C-ABI of include/rt_hip.h over the kernels in
+// rt_kernels.hpp.  One rt_scene owns the device copy of a scene, a HIP stream and a reusable
+// workspace (framebuffer, hit queue, two ping-pong ray queues, counters), so a render call does
+// no allocation once the workspace has grown to the frame size.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_kernels.hpp"
+#include "rt_shade_fast.hpp"
+
+using namespace rt;
+
+static_assert(RT_MAX_LEVELS == MAX_LEVELS, "level caps differ");
+
+// ------------------------------------------------------------------------------- errors --------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP,   \
+                                      "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rt_device_count(int* count) {
+  if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null pointer");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------- scene ---------
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 trace, 1 shade, 2 other
+
+struct PendingFrame {
+  rt_stats* user = nullptr;
+  Counters* h_counters = nullptr;   // pinned slot
+  std::vector<EventPair> events;
+  int levels = 0, n_lights = 0, n_cells = 1, precision = 0;
+  bool timing = false;
+};
+
+struct rt_scene {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int num_cu = 256;
+  DevScene ds{};
+  Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
+  bool all_opaque = true;
+  // workspace
+  size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
+  void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
+  void* d_out = nullptr;         // conversion / staging target
+  HitRec* d_hits = nullptr;
+  double* d_qbuf[2] = {nullptr, nullptr};   // 9*cap_queue doubles each
+  uint32_t* d_qpix[2] = {nullptr, nullptr};
+  Counters* d_counters = nullptr;
+  std::vector<Counters*> h_slots;           // pinned
+  std::deque<PendingFrame> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::mutex mu;
+};
+
+static void free_workspace(rt_scene* s) {
+  if (s->d_fb) hipFree(s->d_fb);
+  if (s->d_out) hipFree(s->d_out);
+  if (s->d_hits) hipFree(s->d_hits);
+  for (int i = 0; i < 2; ++i) { if (s->d_qbuf[i]) hipFree(s->d_qbuf[i]); if (s->d_qpix[i]) hipFree(s->d_qpix[i]); }
+  s->d_fb = s->d_out = nullptr; s->d_hits = nullptr;
+  s->d_qbuf[0] = s->d_qbuf[1] = nullptr; s->d_qpix[0] = s->d_qpix[1] = nullptr;
+  s->cap_pixels = s->cap_queue = s->cap_out = 0;
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+  if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null pointer");
+  *out = nullptr;
+  if (desc->n_surfaces < 0 || desc->n_materials < 0 || desc->n_lights < 0)
+    return fail(RT_ERR_INVALID, "rt_scene_create: negative count");
+  if (desc->n_surfaces > 0 && (!desc->surf_type || !desc->surf_data || !desc->surf_material))
+    return fail(RT_ERR_INVALID, "rt_scene_create: null surface arrays");
+  if ((desc->n_materials > 0 && !desc->materials) || (desc->n_lights > 0 && !desc->lights))
+    return fail(RT_ERR_INVALID, "rt_scene_create: null material/light arrays");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+
+  // type-sort, keeping file order inside each type and the original list index for tie-breaks
+  std::vector<Prim> prims;
+  prims.reserve(desc->n_surfaces);
+  int cnt[3] = {0, 0, 0};
+  for (int type = 0; type < 3; ++type)
+    for (int i = 0; i < desc->n_surfaces; ++i) {
+      int ty = desc->surf_type[i];
+      if (ty < 0 || ty > 2) return fail(RT_ERR_INVALID, "surface %d: unknown type %d", i, ty);
+      if (ty != type) continue;
+      int m = desc->surf_material[i];
+      if (m < 0 || m >= desc->n_materials) return fail(RT_ERR_INVALID, "surface %d: material %d out of range", i, m);
+      Prim p; std::memset(&p, 0, sizeof p);
+      const double* a = desc->surf_data + 8 * (size_t)i;
+      for (int k = 0; k < 6; ++k) p.a[k] = a[k];
+      if (ty == RT_SPHERE) { p.a[4] = a[3] * a[3]; p.a[5] = 0; }
+      if (ty == RT_PLANE) { p.a[4] = p.a[5] = 0; }
+      p.mat = m; p.orig = i; p.type = ty;
+      prims.push_back(p);
+      ++cnt[type];
+    }
+  std::vector<double> mats((size_t)std::max(desc->n_materials, 1) * MAT_STRIDE, 0.0);
+  for (int i = 0; i < desc->n_materials; ++i)
+    for (int k = 0; k < 11; ++k) mats[(size_t)i * MAT_STRIDE + k] = desc->materials[(size_t)i * 11 + k];
+  std::vector<double> lights((size_t)std::max(desc->n_lights, 1) * LIGHT_STRIDE, 0.0);
+  for (int i = 0; i < desc->n_lights; ++i)
+    for (int k = 0; k < 9; ++k) lights[(size_t)i * LIGHT_STRIDE + k] = desc->lights[(size_t)i * 9 + k];
+
+  rt_scene* s = new (std::nothrow) rt_scene();
+  if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
+  s->device = device;
+  auto bail = [&](int code) { rt_scene_destroy(s); return code; };
+#define HIPCHK_S(call)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP, \
+                                           "%s failed: %s", #call, hipGetErrorString(e_)));      \
+  } while (0)
+  HIPCHK_S(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK_S(hipGetDeviceProperties(&prop, device));
+  s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK_S(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->stream = s->own_stream;
+  size_t np = std::max<size_t>(prims.size(), 1);
+  HIPCHK_S(hipMalloc(&s->d_prims, np * sizeof(Prim)));
+  HIPCHK_S(hipMalloc(&s->d_mats, mats.size() * sizeof(double)));
+  HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(double)));
+  HIPCHK_S(hipMalloc(&s->d_counters, sizeof(Counters)));
+  if (!prims.empty()) HIPCHK_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(double), hipMemcpyHostToDevice));
+#undef HIPCHK_S
+  s->ds.prims = s->d_prims; s->ds.mats = s->d_mats; s->ds.lights = s->d_lights;
+  s->ds.nS = cnt[0]; s->ds.nP = cnt[1]; s->ds.nB = cnt[2]; s->ds.n = (int)prims.size();
+  s->ds.nM = desc->n_materials; s->ds.nL = desc->n_lights;
+  for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
+  s->all_opaque = true;
+  for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
+  *out = s;
+  return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  free_workspace(s);
+  if (s->d_prims) hipFree(s->d_prims);
+  if (s->d_mats) hipFree(s->d_mats);
+  if (s->d_lights) hipFree(s->d_lights);
+  if (s->d_counters) hipFree(s->d_counters);
+  for (Counters* h : s->h_slots) hipHostFree(h);
+  for (hipEvent_t e : s->event_pool) hipEventDestroy(e);
+  for (PendingFrame& pf : s->pending) for (EventPair& ep : pf.events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  if (s->own_stream) hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+extern "C" int rt_scene_set_stream(rt_scene* s, void* hip_stream) {
+  if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_stream: null scene");
+  std::lock_guard<std::mutex> lk(s->mu);
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return RT_OK;
+}
+
+extern "C" int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part, int32_t n_parts, int32_t* rows) {
+  if (!rows || height < 0 || block_rows <= 0) return fail(RT_ERR_INVALID, "rt_rows_in_part: bad arguments");
+  if (n_parts <= 1) { *rows = height; return RT_OK; }
+  if (part < 0 || part >= n_parts) return fail(RT_ERR_INVALID, "rt_rows_in_part: part %d of %d", part, n_parts);
+  int full_blocks = height / block_rows, tail = height % block_rows;
+  int mine = full_blocks / n_parts + ((full_blocks % n_parts) > part ? 1 : 0);
+  int r = mine * block_rows;
+  if (tail && (full_blocks % n_parts) == part) r += tail;
+  *rows = r;
+  return RT_OK;
+}
+
+// Finish every pending frame of a scene: wait, fold counters/events into the callers' rt_stats.
+static int drain(rt_scene* s) {
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  int rc = RT_OK;
+  while (!s->pending.empty()) {
+    PendingFrame pf = std::move(s->pending.front());
+    s->pending.pop_front();
+    const Counters& c = *pf.h_counters;
+    if (c.overflow) rc = fail(RT_ERR_QUEUE_OVERFLOW, "bounce queue overflow: render fewer rows per call");
+    if (pf.user) {
+      rt_stats st; std::memset(&st, 0, sizeof st);
+      st.levels = pf.levels;
+      for (int l = 0; l < pf.levels; ++l) {
+        st.level_rays[l] = c.n_rays[l]; st.level_hits[l] = c.n_hits[l];
+        st.rays += c.n_rays[l]; st.hits += c.n_hits[l];
+        if (c.n_rays[l]) st.batches++;
+      }
+      st.shadow_rays = st.hits * (int64_t)pf.n_lights * pf.n_cells;
+      st.segments = pf.precision == RT_FP64 ? (int64_t)c.queries - st.shadow_rays : -1;
+      if (pf.timing && !pf.events.empty()) {
+        for (EventPair& ep : pf.events) {
+          float ms = 0; hipEventElapsedTime(&ms, ep.a, ep.b);
+          if (ep.kind == 0) { st.trace_ms += ms; st.trace_launches++; }
+          else if (ep.kind == 1) { st.shade_ms += ms; st.shade_launches++; }
+          else st.other_ms += ms;
+        }
+        hipEventElapsedTime(&st.total_ms, pf.events.front().a, pf.events.back().b);
+      }
+      *pf.user = st;
+    }
+    for (EventPair& ep : pf.events) { s->event_pool.push_back(ep.a); s->event_pool.push_back(ep.b); }
+    s->h_slots.push_back(pf.h_counters);
+  }
+  return rc;
+}
+
+extern "C" int rt_sync(rt_scene* s) {
+  if (!s) return fail(RT_ERR_INVALID, "rt_sync: null scene");
+  std::lock_guard<std::mutex> lk(s->mu);
+  return drain(s);
+}
+
+static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out) {
+  if (pixels > s->cap_pixels) {
+    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
+    free_workspace(s);
+    s->d_out = keep_out; s->cap_out = keep_cap;
+    size_t q = 2 * pixels + 1024;
+    if (q > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
+    HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
+    HIPCHK(hipMalloc(&s->d_hits, q * sizeof(HitRec)));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipMalloc(&s->d_qbuf[i], q * 9 * sizeof(double)));
+      HIPCHK(hipMalloc(&s->d_qpix[i], q * sizeof(uint32_t)));
+    }
+    s->cap_pixels = pixels; s->cap_queue = q;
+  }
+  if (need_out && out_bytes > s->cap_out) {
+    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    if (s->d_out) hipFree(s->d_out);
+    s->d_out = nullptr; s->cap_out = 0;
+    HIPCHK(hipMalloc(&s->d_out, out_bytes));
+    s->cap_out = out_bytes;
+  }
+  return RT_OK;
+}
+
+static RayQueue make_queue(rt_scene* s, int which) {
+  RayQueue q; double* b = s->d_qbuf[which]; size_t c = s->cap_queue;
+  q.ox = b; q.oy = b + c; q.oz = b + 2 * c; q.dx = b + 3 * c; q.dy = b + 4 * c; q.dz = b + 5 * c;
+  q.wx = b + 6 * c; q.wy = b + 7 * c; q.wz = b + 8 * c; q.pix = s->d_qpix[which];
+  return q;
+}
+
+static DevCamera to_dev_camera(const rt_camera* c) {
+  DevCamera d;
+  for (int k = 0; k < 3; ++k) { d.pos[k] = c->pos[k]; d.fwd[k] = c->forward[k]; d.right[k] = c->right[k]; d.up[k] = c->up[k]; }
+  d.sdist = c->screen_distance; d.swidth = c->screen_width; d.sheight = c->screen_height;
+  return d;
+}
+
+static hipEvent_t get_event(rt_scene* s) {
+  if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
+
+struct Timed {   // RAII-ish helper: bracket one launch with events when timing is on
+  rt_scene* s; PendingFrame* pf; int kind; hipEvent_t a = nullptr, b = nullptr;
+  Timed(rt_scene* s_, PendingFrame* pf_, int kind_) : s(s_), pf(pf_), kind(kind_) {
+    if (pf->timing) { a = get_event(s); b = get_event(s); hipEventRecord(a, s->stream); }
+  }
+  ~Timed() { if (pf->timing) { hipEventRecord(b, s->stream); pf->events.push_back({a, b, kind}); } }
+};
+
+template <typename FB>
+static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp, const rt_frame* fr, FB* fb,
+                        PendingFrame* pf) {
+  const bool lds = s->ds.n <= LDS_PRIMS;
+  const int grid = s->num_cu * 8;
+  RayQueue q[2] = {make_queue(s, 0), make_queue(s, 1)};
+  const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
+  { Timed t(s, pf, 2); hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(256), 0, s->stream, s->d_counters, P); }
+  for (int level = 0; level <= fp.max_depth; ++level) {
+    RayQueue cur = q[level & 1], nxt = q[(level + 1) & 1];
+    int tgrid = grid;
+    if (level == 0) tgrid = (int)std::min<size_t>((size_t)grid, ((size_t)P + BLOCK - 1) / BLOCK);
+    if (tgrid < 1) tgrid = 1;
+    {
+      Timed t(s, pf, 0);
+      if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
+      else hipLaunchKernelGGL((k_trace<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
+    }
+    {
+      Timed t(s, pf, 1);
+      if (fr->precision == RT_FP64) {
+        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
+        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
+      } else {
+        launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, tgrid, s->stream);
+      }
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
+                         rt_stats* stats) {
+  if (!s || !camera || !fr || !out) return fail(RT_ERR_INVALID, "rt_render: null pointer");
+  if (fr->width <= 0 || fr->height <= 0) return fail(RT_ERR_INVALID, "rt_render: bad image size %dx%d", fr->width, fr->height);
+  if (fr->block_rows <= 0) return fail(RT_ERR_INVALID, "rt_render: block_rows must be >= 1");
+  if (fr->max_depth < 0 || fr->max_depth + 1 > MAX_LEVELS) return fail(RT_ERR_INVALID, "rt_render: max_depth %d outside [0,%d]", fr->max_depth, MAX_LEVELS - 1);
+  if (fr->n_shadow < 0 || fr->n_shadow > 64) return fail(RT_ERR_INVALID, "rt_render: n_shadow %d outside [0,64]", fr->n_shadow);
+  if (fr->precision != RT_FP64 && fr->precision != RT_FP32) return fail(RT_ERR_INVALID, "rt_render: unknown precision %d", fr->precision);
+  if (fr->out_format < RT_OUT_F64 || fr->out_format > RT_OUT_U8) return fail(RT_ERR_INVALID, "rt_render: unknown out_format %d", fr->out_format);
+  if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM)
+    return fail(RT_ERR_INVALID, "rt_render: the numpy-stream jitter mode is not available in this build; use pixel-keyed jitter");
+  if (fr->jitter_mode != RT_JITTER_PIXEL_KEYED) return fail(RT_ERR_INVALID, "rt_render: unknown jitter mode %d", fr->jitter_mode);
+  if ((fr->flags & RT_FLAG_ASYNC) && !out_is_device) return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_ASYNC needs a device output buffer");
+  int32_t rows = 0;
+  int rc = rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, &rows);
+  if (rc != RT_OK) return rc;
+
+  std::lock_guard<std::mutex> lk(s->mu);
+  HIPCHK(hipSetDevice(s->device));
+  const size_t pixels = (size_t)rows * fr->width, nval = pixels * 3;
+  if (pixels == 0) { if (stats) std::memset(stats, 0, sizeof *stats); return RT_OK; }
+  const size_t esz = fr->out_format == RT_OUT_F64 ? 8 : (fr->out_format == RT_OUT_F32 ? 4 : 1);
+  const bool fb_is_double = fr->precision == RT_FP64;
+  const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
+  const bool direct = native && out_is_device;            // render straight into the caller's buffer
+  const bool need_out = !native;                           // conversion target on the device
+  rc = ensure_workspace(s, pixels, nval * esz, need_out && !out_is_device);
+  if (rc != RT_OK) return rc;
+  if (s->pending.size() >= 48) { rc = drain(s); if (rc != RT_OK) return rc; }
+
+  PendingFrame pf;
+  pf.user = stats; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
+  pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
+  pf.precision = fr->precision; pf.timing = (fr->flags & RT_FLAG_TIMING) != 0;
+  if (s->h_slots.empty()) { Counters* h = nullptr; HIPCHK(hipHostMalloc(&h, sizeof(Counters))); s->h_slots.push_back(h); }
+  pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
+
+  FrameParams fp;
+  fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
+  fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
+  fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)s->cap_queue;
+  DevCamera cam = to_dev_camera(camera);
+
+  void* fb = direct ? out : s->d_fb;
+  rc = fb_is_double ? launch_frame<double>(s, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, cam, fp, fr, (float*)fb, &pf);
+  if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
+
+  if (!direct) {
+    void* dst = out_is_device ? out : (native ? nullptr : s->d_out);
+    if (!native) {
+      Timed t(s, &pf, 2);
+      const int cg = (int)std::min<size_t>((nval + BLOCK - 1) / BLOCK, (size_t)s->num_cu * 16);
+      if (fb_is_double) {
+        if (fr->out_format == RT_OUT_F32) hipLaunchKernelGGL((k_convert<double, float>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (float*)dst, nval);
+        else hipLaunchKernelGGL((k_convert<double, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (unsigned char*)dst, nval);
+      } else {
+        if (fr->out_format == RT_OUT_F64) hipLaunchKernelGGL((k_convert<float, double>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (double*)dst, nval);
+        else hipLaunchKernelGGL((k_convert<float, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (unsigned char*)dst, nval);
+      }
+    }
+    if (!out_is_device) HIPCHK(hipMemcpyAsync(out, native ? fb : s->d_out, nval * esz, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIPCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+  s->pending.push_back(std::move(pf));
+  if (fr->flags & RT_FLAG_ASYNC) return RT_OK;
+  return drain(s);
+}
+
+// ------------------------------------------------------------------- utility exports -----------
+template <typename F>
+static int with_device_arrays(rt_scene* s, F&& body) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  HIPCHK(hipSetDevice(s->device));
+  int rc = drain(s);
+  if (rc != RT_OK) return rc;
+  return body();
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+extern "C" int rt_nearest_hit(rt_scene* s, const double* origins, const double* dirs, int64_t M, double* t_out,
+                              int32_t* idx_out, double* normals_out) {
+  if (!s || M < 0 || (M > 0 && (!origins || !dirs || !t_out || !idx_out || !normals_out)))
+    return fail(RT_ERR_INVALID, "rt_nearest_hit: bad arguments");
+  if (M == 0) return RT_OK;
+  return with_device_arrays(s, [&]() -> int {
+    DevBuf o, d, t, i, n;
+    HIPCHK(o.alloc(M * 24)); HIPCHK(d.alloc(M * 24)); HIPCHK(t.alloc(M * 8)); HIPCHK(i.alloc(M * 4)); HIPCHK(n.alloc(M * 24));
+    HIPCHK(hipMemcpyAsync(o.p, origins, M * 24, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(d.p, dirs, M * 24, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_nearest_rays, dim3((unsigned)((M + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s->stream, s->ds,
+                       (const double*)o.p, (const double*)d.p, (long long)M, (double*)t.p, (int*)i.p, (double*)n.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t_out, t.p, M * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(idx_out, i.p, M * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(normals_out, n.p, M * 24, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+  });
+}
+
+extern "C" int rt_shadow_transmission(rt_scene* s, const double* origins, const double* dirs, const double* max_dist,
+                                      int64_t M, double* out) {
+  if (!s || M < 0 || (M > 0 && (!origins || !dirs || !max_dist || !out)))
+    return fail(RT_ERR_INVALID, "rt_shadow_transmission: bad arguments");
+  if (M == 0) return RT_OK;
+  return with_device_arrays(s, [&]() -> int {
+    DevBuf o, d, m, r;
+    HIPCHK(o.alloc(M * 24)); HIPCHK(d.alloc(M * 24)); HIPCHK(m.alloc(M * 8)); HIPCHK(r.alloc(M * 8));
+    HIPCHK(hipMemcpyAsync(o.p, origins, M * 24, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(d.p, dirs, M * 24, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(m.p, max_dist, M * 8, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_shadow_rays, dim3((unsigned)((M + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s->stream, s->ds,
+                       (const double*)o.p, (const double*)d.p, (const double*)m.p, (long long)M, (double*)r.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, r.p, M * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+  });
+}
+
+extern "C" int rt_camera_rays(rt_scene* s, const rt_camera* camera, int32_t W, int32_t H, int32_t y0, int32_t y1,
+                              double* origins_out, double* dirs_out) {
+  if (!s || !camera || W <= 0 || H <= 0 || y0 < 0 || y1 < y0 || !origins_out || !dirs_out)
+    return fail(RT_ERR_INVALID, "rt_camera_rays: bad arguments");
+  const int64_t M = (int64_t)(y1 - y0) * W;
+  if (M == 0) return RT_OK;
+  return with_device_arrays(s, [&]() -> int {
+    DevBuf o, d;
+    HIPCHK(o.alloc(M * 24)); HIPCHK(d.alloc(M * 24));
+    hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((M + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s->stream,
+                       to_dev_camera(camera), W, H, y0, (long long)M, (double*)o.p, (double*)d.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(origins_out, o.p, M * 24, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(dirs_out, d.p, M * 24, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RT_OK;
+  });
+}

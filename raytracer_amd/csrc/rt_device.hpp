@@ -1,0 +1,248 @@
+// rt_device.hpp — device-side scene records and the exact (IEEE double) geometry of the hot path.
+//
+// Every function cites the reference lines it implements (paths under the reference checkout).
+// The fp64 functions keep the reference's evaluation order — np.sum(x*y,axis=1) is
+// (x0*y0 + x1*y1) + x2*y2, np.linalg.norm is sqrt((x*x+y*y)+z*z) — and this file is compiled
+// with -ffp-contract=off, so their results are bit-identical to NumPy's wherever NumPy itself is
+// deterministic.  Code that wants fused multiply-adds calls fma() explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+constexpr double EPS = 1e-6;       // ray_tracer.py:14
+constexpr double HIT_EPS = 1e-6;   // sphere.py:70-71, infinite_plane.py:42, cube.py:112-120
+constexpr double PAR_EPS = 1e-10;  // infinite_plane.py:35, cube.py:80,128
+constexpr int WALK_CAP = 20;       // ray_tracer.py:257
+#define RT_INF __builtin_huge_val()
+
+// One primitive, 64 bytes.  Records are sorted by type on the device (spheres, planes, boxes), each
+// group in scene-file order; `orig` is the index in the caller's surface list and breaks ties the
+// way the reference's list-order loop with a strict '<' does (ray_tracer.py:119-125).
+struct __attribute__((aligned(16))) Prim {
+  double a[6];   // sphere: cx cy cz r r*r - | plane: nx ny nz offset - - | box: min xyz, max xyz
+  int32_t mat;   // 0-based material index
+  int32_t orig;  // index in the original surface list
+  int32_t type;
+  int32_t pad;
+};
+static_assert(sizeof(Prim) == 64, "Prim must be 64 bytes");
+
+struct DevScene {
+  const Prim* prims;      // device memory, type-sorted
+  const double* mats;     // [nM][12]: diffuse rgb, specular rgb, reflection rgb, shininess, transparency, pad
+  const double* lights;   // [nL][12]: pos xyz, color rgb, specular, shadow, radius, pad
+  int32_t nS, nP, nB, n;  // counts per type and total
+  int32_t nM, nL;
+  double bg[3];
+};
+constexpr int MAT_STRIDE = 12;
+constexpr int LIGHT_STRIDE = 12;
+
+struct DevCamera {
+  double pos[3], fwd[3], right[3], up[3];
+  double sdist, swidth, sheight;
+};
+
+struct d3 { double x, y, z; };
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ double norm3(d3 a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {  // np.cross
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double comp(d3 v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); }
+
+// ----------------------------------------------------------------- pixel-keyed jitter (mode B) --
+// Same mixer as raytracer_amd/jitter.py and oracle/rt_oracle.c.
+__host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
+}
+__host__ __device__ __forceinline__ uint32_t jit_light_key(uint32_t seed, uint32_t pixel, uint32_t depth, uint32_t light) {
+  uint32_t h = lowbias32(pixel ^ seed);
+  h = lowbias32(h + depth);
+  return lowbias32(h + light);
+}
+__host__ __device__ __forceinline__ uint32_t jit_cell_bits(uint32_t key, uint32_t cell) {
+  return lowbias32(key + (cell + 1u) * 0x9E3779B9u);   // u_i = bits>>16, u_j = bits&0xFFFF, scaled by 2^-16
+}
+
+// ------------------------------------------------------------------------ primitives, t only ---
+// Sphere.intersect_batch, surfaces/sphere.py:49-71.
+__device__ __forceinline__ double sphere_t(const Prim& s, d3 o, d3 d) {
+  d3 oc = mk3(o.x - s.a[0], o.y - s.a[1], o.z - s.a[2]);
+  double a = dot3(d, d);
+  double b = 2.0 * dot3(oc, d);
+  double c = dot3(oc, oc) - s.a[4];            // a[4] = r*r (same double the reference computes)
+  double disc = b * b - (4 * a) * c;
+  if (!(disc >= 0)) return RT_INF;
+  double sq = sqrt(disc);
+  double t1 = (-b - sq) / (2 * a);
+  double t2 = (-b + sq) / (2 * a);
+  double t = (t1 > HIT_EPS) ? t1 : t2;
+  return (t > HIT_EPS) ? t : RT_INF;
+}
+// sphere.py:80-90: outward normal at the hit, flipped to face the ray.
+__device__ __forceinline__ d3 sphere_normal(const Prim& s, d3 o, d3 d, double t) {
+  double r = s.a[3];
+  d3 hp = mk3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+  d3 n = mk3((hp.x - s.a[0]) / r, (hp.y - s.a[1]) / r, (hp.z - s.a[2]) / r);
+  if (dot3(d, n) > 0) n = mk3(-n.x, -n.y, -n.z);
+  return n;
+}
+
+// InfinitePlane.intersect_batch, surfaces/infinite_plane.py:30-49.
+__device__ __forceinline__ double plane_t(const Prim& p, d3 o, d3 d) {
+  d3 N = mk3(p.a[0], p.a[1], p.a[2]);
+  double den = dot3(d, N);
+  if (!(fabs(den) >= PAR_EPS)) return RT_INF;
+  double t = (p.a[3] - dot3(o, N)) / den;
+  return (t > HIT_EPS) ? t : RT_INF;
+}
+__device__ __forceinline__ d3 plane_normal(const Prim& p, d3 d) {   // infinite_plane.py:51-56
+  d3 N = mk3(p.a[0], p.a[1], p.a[2]);
+  return dot3(d, N) > 0 ? mk3(-N.x, -N.y, -N.z) : N;
+}
+
+// Cube.intersect_batch, surfaces/cube.py:64-136.  WANT_N: also produce the face normal.
+template <bool WANT_N>
+__device__ __forceinline__ double box_hit(const Prim& b, d3 o, d3 d, d3* n_out) {
+  double tmin = -RT_INF, tmax = RT_INF, sign = 1.0;
+  int axis = 0;
+  bool valid = true;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    double dv = comp(d, ax), ov = comp(o, ax);
+    bool parallel = fabs(dv) < PAR_EPS;
+    bool outside = (ov < b.a[ax]) || (ov > b.a[3 + ax]);
+    if (parallel && outside) valid = false;                    // cube.py:80-82
+    if (!parallel && valid) {                                  // cube.py:84
+      double t1 = (b.a[ax] - ov) / dv;
+      double t2 = (b.a[3 + ax] - ov) / dv;
+      double sg = (t1 > t2) ? 1.0 : -1.0;
+      double tn = fmin(t1, t2), tf = fmax(t1, t2);
+      if (tn > tmin) { tmin = tn; axis = ax; sign = sg; }      // strict: earlier axis wins ties
+      tmax = fmin(tmax, tf);
+      valid = valid && (tmin <= tmax);
+    }
+  }
+  if (WANT_N) *n_out = mk3(0, 0, 0);
+  if (!valid) return RT_INF;
+  if (tmin >= HIT_EPS) {                                       // cube.py:113-118
+    if (WANT_N) *n_out = mk3(axis == 0 ? sign : 0.0, axis == 1 ? sign : 0.0, axis == 2 ? sign : 0.0);
+    return tmin;
+  }
+  if (tmax >= HIT_EPS) {                                       // origin inside: cube.py:120-134
+    if (WANT_N) {
+      bool done = false;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double dv = comp(d, ax), ov = comp(o, ax);
+        if (done || fabs(dv) < PAR_EPS) continue;
+        double t1 = (b.a[ax] - ov) / dv;
+        double t2 = (b.a[3 + ax] - ov) / dv;
+        double far = (t1 > t2) ? t1 : t2;
+        if (fabs(far - tmax) < HIT_EPS) {
+          double s = (t2 > t1) ? 1.0 : -1.0;
+          *n_out = mk3(ax == 0 ? s : 0.0, ax == 1 ? s : 0.0, ax == 2 ? s : 0.0);
+          done = true;
+        }
+      }
+    }
+    return tmax;
+  }
+  return RT_INF;
+}
+
+// ------------------------------------------------------------------------------ nearest hit ---
+// find_nearest_intersection_batch, ray_tracer.py:112-127.  The reference walks the surface list in
+// file order and replaces on a strict '<'; on the type-sorted records that is the lexicographic
+// minimum of (t, orig).  Returns t (INF = miss) and the *sorted* record index (-1 = miss).
+__device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out) {
+  double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
+  int k = 0;
+  for (int e = nS; k < e; ++k) {
+    double t = sphere_t(P[k], o, d);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  for (int e = nS + nP; k < e; ++k) {
+    double t = plane_t(P[k], o, d);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  for (int e = nS + nP + nB; k < e; ++k) {
+    double t = box_hit<false>(P[k], o, d, nullptr);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  *k_out = bk;
+  return best;
+}
+
+__device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
+  if (p.type == 0) return sphere_normal(p, o, d, t);
+  if (p.type == 1) return plane_normal(p, d);
+  d3 n; box_hit<true>(p, o, d, &n); return n;
+}
+
+// compute_shadow_transmission_batch, ray_tracer.py:247-293, for one ray.
+__device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
+                                              const double* __restrict__ mats, d3 o, d3 d, double maxdist,
+                                              int* queries) {
+  double remaining = maxdist, trans = 1.0;
+  for (int step = 0; step < WALK_CAP; ++step) {
+    int k; double t = nearest(P, nS, nP, nB, o, d, &k);
+    ++*queries;
+    if (!((t < remaining) && k >= 0)) break;                     // :269-272, :290-291
+    trans *= mats[MAT_STRIDE * P[k].mat + 10];                   // :276-279
+    if (trans < EPS) break;                                      // :281 (value kept)
+    double adv = t + EPS;                                        // :287-288
+    o = mk3(o.x + d.x * adv, o.y + d.y * adv, o.z + d.z * adv);
+    remaining -= adv;
+  }
+  return trans;
+}
+
+// Camera.generate_all_rays / generate_rays_for_rows, camera.py:46-104: unit direction of pixel (x, y).
+__device__ __forceinline__ d3 camera_dir(const DevCamera& c, int W, int H, int x, int y) {
+  double px = 0.5 - ((double)x + 0.5) / W;
+  double py = 0.5 - ((double)y + 0.5) / H;
+  px *= c.swidth;
+  py *= c.sheight;
+  double v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double center = c.pos[k] + c.fwd[k] * c.sdist;
+    double sp = (center + px * c.right[k]) + py * c.up[k];
+    v[k] = sp - c.pos[k];
+  }
+  d3 vv = mk3(v[0], v[1], v[2]);
+  double nrm = norm3(vv);
+  return mk3(vv.x / nrm, vv.y / nrm, vv.z / nrm);
+}
+
+// Row sets (include/rt_hip.h, rt_frame): local row -> global row.
+struct RowSet { int32_t W, H, block_rows, part, n_parts, rows; };
+__host__ __device__ __forceinline__ int rowset_global_y(const RowSet& rs, int local_row) {
+  if (rs.n_parts <= 1) return local_row;
+  int b = local_row / rs.block_rows, r = local_row - b * rs.block_rows;
+  return (b * rs.n_parts + rs.part) * rs.block_rows + r;
+}
+
+// Wave64-aggregated queue append: one atomic per wave (ballot + mbcnt prefix).  Every lane of the
+// wave must call it (pred false for lanes with nothing to append).  Returns the slot for this lane.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0) return 0;
+  uint32_t cnt = (uint32_t)__popcll(mask);
+  uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)__lane_id() == leader) base = atomicAdd(counter, cnt);
+  base = __shfl(base, leader);
+  return base + prefix;
+}
+
+}  // namespace rt

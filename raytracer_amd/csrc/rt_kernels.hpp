@@ -1,0 +1,331 @@
+// rt_kernels.hpp — the wavefront kernels of the renderer (gfx950, wave64).
+//
+// Frame schedule (pixel-keyed jitter): for level = 0 .. max_depth
+//     k_trace  : one lane per radiance ray -> nearest hit; misses add weight*background to the
+//                framebuffer; hits are compacted into a dense hit queue (ballot + one atomic/wave)
+//     k_shade_*: one lane per hit -> soft shadows + Phong for every light, accumulate into the
+//                framebuffer, spawn transparency / reflection children into the next level's ray
+//                queue (same wave-aggregated append)
+// which is the reference's loop over its LIFO stack of ray batches (ray_tracer.py:479-595) with the
+// batches of one depth merged — legal because pixel-keyed jitter makes rays independent.
+// Waves pull work in 64-item grabs from a device-side cursor, so no level size ever returns to the
+// host inside a frame.
+#pragma once
+#include "rt_device.hpp"
+
+namespace rt {
+
+constexpr int MAX_LEVELS = 32;
+constexpr int BLOCK = 256;
+constexpr int LDS_PRIMS = 128;   // scenes up to this many primitives are staged in LDS (8 KiB)
+
+struct Counters {
+  uint32_t n_rays[MAX_LEVELS + 1];
+  uint32_t n_hits[MAX_LEVELS + 1];
+  uint32_t work_trace[MAX_LEVELS + 1];
+  uint32_t work_shade[MAX_LEVELS + 1];
+  unsigned long long queries;   // shadow-walk nearest-hit queries (fp64 kernels)
+  uint32_t overflow;
+  uint32_t pad;
+};
+
+// Radiance-ray queue of one level, struct-of-arrays so that a wave's loads/stores coalesce.
+struct RayQueue {
+  double *ox, *oy, *oz, *dx, *dy, *dz, *wx, *wy, *wz;
+  uint32_t* pix;   // local pixel index (row-set framebuffer index)
+};
+
+struct __attribute__((aligned(16))) HitRec {
+  uint32_t slot;   // ray slot in the level's queue (level 0: local pixel index)
+  int32_t prim;    // sorted primitive record index
+  double t;
+};
+
+struct FrameParams {
+  RowSet rs;
+  int32_t n_shadow, max_depth;
+  uint32_t seed;
+  uint32_t queue_cap;
+};
+
+__device__ __forceinline__ uint32_t global_pixel(const RowSet& rs, uint32_t lp) {
+  uint32_t lr = lp / (uint32_t)rs.W, x = lp - lr * (uint32_t)rs.W;
+  return (uint32_t)rowset_global_y(rs, (int)lr) * (uint32_t)rs.W + x;
+}
+
+// Stage the primitive records in LDS when the scene is small; otherwise read them from global
+// memory (wave-uniform addresses -> scalar loads).  Returns the pointer the kernel should use.
+template <bool LDS_SCENE>
+__device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds) {
+  if (!LDS_SCENE) return sc.prims;
+  const int words = sc.n * (int)(sizeof(Prim) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  return lds;
+}
+
+// Wave-level dynamic work grab: returns the base index of a 64-item chunk (all lanes get it).
+__device__ __forceinline__ uint32_t grab64(uint32_t* cursor) {
+  uint32_t base = 0;
+  if (__lane_id() == 0) base = atomicAdd(cursor, 64u);
+  return __shfl(base, 0);
+}
+
+template <typename FB>
+__device__ __forceinline__ void fb_add(FB* fb, uint32_t lp, double r, double g, double b) {
+  atomicAdd(&fb[3 * (size_t)lp + 0], (FB)r);
+  atomicAdd(&fb[3 * (size_t)lp + 1], (FB)g);
+  atomicAdd(&fb[3 * (size_t)lp + 2], (FB)b);
+}
+
+struct RayIn { d3 o, d, w; uint32_t lp; };
+
+__device__ __forceinline__ RayIn load_ray(int level, uint32_t slot, const DevCamera& cam, const RowSet& rs, const RayQueue& q) {
+  RayIn r;
+  if (level == 0) {
+    uint32_t lr = slot / (uint32_t)rs.W, x = slot - lr * (uint32_t)rs.W;
+    r.o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    r.d = camera_dir(cam, rs.W, rs.H, (int)x, rowset_global_y(rs, (int)lr));
+    r.w = mk3(1.0, 1.0, 1.0);
+    r.lp = slot;
+  } else {
+    r.o = mk3(q.ox[slot], q.oy[slot], q.oz[slot]);
+    r.d = mk3(q.dx[slot], q.dy[slot], q.dz[slot]);
+    r.w = mk3(q.wx[slot], q.wy[slot], q.wz[slot]);
+    r.lp = q.pix[slot];
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------- k_trace -------
+// Primary-ray generation (level 0) / queue read, brute-force nearest hit, miss -> background,
+// hit compaction.  ray_tracer.py:491-515 and camera.py:46-73.
+template <typename FB, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                 HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
+  __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  uint32_t count = C->n_rays[level];
+  if (count > fp.queue_cap) count = fp.queue_cap;
+  const uint32_t lane = __lane_id();
+  for (;;) {
+    uint32_t base = grab64(&C->work_trace[level]);
+    if (base >= count) break;
+    uint32_t slot = base + lane;
+    bool active = slot < count;
+    bool hit = false;
+    int k = -1; double t = RT_INF;
+    if (active) {
+      RayIn r = load_ray(level, slot, cam, fp.rs, q);
+      t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k);
+      hit = k >= 0;
+      if (level == 0) {
+        // every pixel has exactly one level-0 ray: plain store initialises the framebuffer
+        // (0 + 1*bg == bg exactly; hit pixels start from 0 and are added to by the shade kernels)
+        fb[3 * (size_t)r.lp + 0] = hit ? (FB)0 : (FB)sc.bg[0];
+        fb[3 * (size_t)r.lp + 1] = hit ? (FB)0 : (FB)sc.bg[1];
+        fb[3 * (size_t)r.lp + 2] = hit ? (FB)0 : (FB)sc.bg[2];
+      } else if (!hit) {
+        fb_add(fb, r.lp, r.w.x * sc.bg[0], r.w.y * sc.bg[1], r.w.z * sc.bg[2]);   // :500-502
+      }
+    }
+    uint32_t hslot = wave_append(&C->n_hits[level], hit);
+    if (hit) {
+      if (hslot < fp.queue_cap) { HitRec h; h.slot = slot; h.prim = k; h.t = t; hits[hslot] = h; }
+      else C->overflow = 1u;
+    }
+  }
+}
+
+// Spawn the children of one shaded hit (ray_tracer.py:565-595) into the next level's queue.
+// Must be called convergently by every lane of the wave.
+__device__ __forceinline__ void spawn_children(bool active, int level, const FrameParams& fp, const double* mat,
+                                               const RayIn& r, d3 hp, d3 n, RayQueue& nq, Counters* C) {
+  bool deeper = active && level < fp.max_depth;
+  bool needT = deeper && (mat[10] > EPS);
+  bool needR = deeper && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS);
+  uint32_t sT = wave_append(&C->n_rays[level + 1], needT);
+  if (needT) {
+    if (sT < fp.queue_cap) {
+      nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
+      nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
+      nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
+      nq.pix[sT] = r.lp;
+    } else C->overflow = 1u;
+  }
+  uint32_t sR = wave_append(&C->n_rays[level + 1], needR);
+  if (needR) {
+    if (sR < fp.queue_cap) {
+      double dn = dot3(r.d, n);                                    // reflect_batch, :34-36
+      nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
+      nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
+      nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
+      nq.pix[sR] = r.lp;
+    } else C->overflow = 1u;
+  }
+}
+
+// ------------------------------------------------------------------------- k_shade_exact -------
+// fp64 shading of a hit queue: literal restatement of ray_tracer.py:517-563 with
+// compute_soft_shadow_batch (:171-244) and compute_shadow_transmission_batch (:247-293) inlined per
+// hit.  Used by precision = RT_FP64.
+template <typename FB, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
+                                                       FB* __restrict__ fb) {
+  __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  uint32_t count = C->n_hits[level];
+  if (count > fp.queue_cap) count = fp.queue_cap;
+  const uint32_t lane = __lane_id();
+  const int n_sh = fp.n_shadow;
+  for (;;) {
+    uint32_t base = grab64(&C->work_shade[level]);
+    if (base >= count) break;
+    uint32_t h = base + lane;
+    bool active = h < count;
+    RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0);
+    const double* mat = sc.mats;
+    r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
+    if (active) {
+      HitRec hr = hits[h];
+      r = load_ray(level, hr.slot, cam, fp.rs, q);
+      const Prim& pr = P[hr.prim];
+      const double t = hr.t;
+      n = prim_normal(pr, r.o, r.d, t);
+      hp = mk3(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);              // :517
+      mat = sc.mats + MAT_STRIDE * pr.mat;
+      d3 v = mk3(r.o.x - hp.x, r.o.y - hp.y, r.o.z - hp.z);                            // :519
+      double vn = norm3(v); if (vn < EPS) vn = EPS;
+      v = mk3(v.x / vn, v.y / vn, v.z / vn);
+      const uint32_t gpix = global_pixel(fp.rs, r.lp);
+      const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);          // :538
+      double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+      int queries = 0;
+      for (int li = 0; li < sc.nL; ++li) {                                             // :526
+        const double* lg = sc.lights + LIGHT_STRIDE * li;
+        const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+        double T;
+        if (n_sh <= 1) {                                                               // :184-196
+          d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
+          double dist = norm3(tl);
+          d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
+          d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+          T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, &queries);
+        } else {
+          d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
+          double ldist = norm3(tl);
+          d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+          d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);                  // :202-205
+          d3 right = cross3(ld, ref);                                                  // :207-209
+          double rn = norm3(right); if (rn < EPS) rn = EPS;
+          right = mk3(right.x / rn, right.y / rn, right.z / rn);
+          d3 up = cross3(right, ld);                                                   // :211-213
+          double un = norm3(up); if (un < EPS) un = EPS;
+          up = mk3(up.x / un, up.y / un, up.z / un);
+          const double radius = lg[8];
+          const double cell = radius / n_sh;                                           // :215
+          const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+          double total = 0.0;
+          for (int i = 0; i < n_sh; ++i)
+            for (int j = 0; j < n_sh; ++j) {                                           // :219-241
+              uint32_t bits = jit_cell_bits(key, (uint32_t)(i * n_sh + j));
+              double ui = (double)(bits >> 16) * (1.0 / 65536.0);
+              double uj = (double)(bits & 0xFFFFu) * (1.0 / 65536.0);
+              double oi = -radius / 2 + cell * (i + ui);
+              double oj = -radius / 2 + cell * (j + uj);
+              d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,
+                          (Lp.z + oi * right.z) + oj * up.z);
+              d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+              double dist = norm3(ts);
+              d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
+              d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+              total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, &queries);
+            }
+          T = total / (double)(n_sh * n_sh);                                           // :243
+        }
+        double I = (1 - lg[7]) + lg[7] * T;                                            // :543
+        d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
+        double ldist = norm3(tl);
+        d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+        d3 ml = mk3(-l.x, -l.y, -l.z);
+        double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
+        double s1 = I * ndl;
+        dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
+        double dn = dot3(ml, n);                                                       // :549
+        d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
+        double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
+        double s2 = I * pow(rdv, mat[9]);                                              // :555-556
+        spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
+        spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
+      }
+      double one_m = 1 - mat[10];                                                      // :562-563
+      fb_add(fb, r.lp, r.w.x * ((dif[0] + spc[0]) * one_m), r.w.y * ((dif[1] + spc[1]) * one_m),
+             r.w.z * ((dif[2] + spc[2]) * one_m));
+      atomicAdd(&C->queries, (unsigned long long)queries);
+    }
+    spawn_children(active, level, fp, mat, r, hp, n, nq, C);
+  }
+}
+
+// --------------------------------------------------------------------- utility kernels ---------
+__global__ void k_init_counters(Counters* C, uint32_t n_level0) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(C);
+  for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) w[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) C->n_rays[0] = n_level0;
+}
+
+// Output conversion; U8 is the reference's save_image quantiser (ray_tracer.py:607-608):
+// clip to [0,1], x255, truncate toward zero.
+template <typename FB, typename OUT>
+__global__ __launch_bounds__(BLOCK) void k_convert(const FB* __restrict__ fb, OUT* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double v = (double)fb[i];
+    if (sizeof(OUT) == 1) {
+      v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+      out[i] = (OUT)(int)(v * 255.0);
+    } else {
+      out[i] = (OUT)v;
+    }
+  }
+}
+
+// rt_nearest_hit: find_nearest_intersection_batch on caller-supplied rays (AoS (M,3) doubles).
+__global__ __launch_bounds__(BLOCK) void k_nearest_rays(DevScene sc, const double* __restrict__ o, const double* __restrict__ d,
+                                                        long long M, double* t_out, int* idx_out, double* n_out) {
+  long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  d3 ro = mk3(o[3 * m], o[3 * m + 1], o[3 * m + 2]), rd = mk3(d[3 * m], d[3 * m + 1], d[3 * m + 2]);
+  int k; double t = nearest(sc.prims, sc.nS, sc.nP, sc.nB, ro, rd, &k);
+  d3 n = mk3(0, 0, 0);
+  if (k >= 0) n = prim_normal(sc.prims[k], ro, rd, t);
+  t_out[m] = t;
+  idx_out[m] = k >= 0 ? sc.prims[k].orig : -1;
+  n_out[3 * m] = n.x; n_out[3 * m + 1] = n.y; n_out[3 * m + 2] = n.z;
+}
+
+// rt_shadow_transmission: compute_shadow_transmission_batch on caller-supplied rays.
+__global__ __launch_bounds__(BLOCK) void k_shadow_rays(DevScene sc, const double* __restrict__ o, const double* __restrict__ d,
+                                                       const double* __restrict__ maxd, long long M, double* out) {
+  long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int q = 0;
+  out[m] = shadow_walk(sc.prims, sc.nS, sc.nP, sc.nB, sc.mats, mk3(o[3 * m], o[3 * m + 1], o[3 * m + 2]),
+                       mk3(d[3 * m], d[3 * m + 1], d[3 * m + 2]), maxd[m], &q);
+}
+
+// rt_camera_rays: Camera.generate_rays_for_rows.
+__global__ __launch_bounds__(BLOCK) void k_camera_rays(DevCamera cam, int W, int H, int y0, long long M, double* o, double* d) {
+  long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int y = y0 + (int)(m / W), x = (int)(m % W);
+  d3 dir = camera_dir(cam, W, H, x, y);
+  o[3 * m] = cam.pos[0]; o[3 * m + 1] = cam.pos[1]; o[3 * m + 2] = cam.pos[2];
+  d[3 * m] = dir.x; d[3 * m + 1] = dir.y; d[3 * m + 2] = dir.z;
+}
+
+}  // namespace rt

@@ -1,0 +1,244 @@
+// rt_shade_fast.hpp — the fp32 shading kernel (precision = RT_FP32), the dominant kernel of a frame.
+//
+// Same inputs/outputs as k_shade_exact, different arithmetic plan (results within the fp32-mode
+// tolerance of BASELINE.json: <= 1/255 per 8-bit channel):
+//
+//  * One lane per hit.  Per light the n x n shadow samples are processed in register-resident
+//    chunks of CH samples; the loop nest is  light -> chunk -> primitive -> sample  so that
+//    everything that depends on (hit, primitive) is computed once per chunk and reused CH times.
+//  * Robustness without fp64 in the inner loop: the quantities in which the reference's 1e-6
+//    offsets live — origin-to-centre vector and |oc|^2 - r^2 of a sphere, signed plane distance,
+//    slab offsets of a box — are formed in fp64 from the fp64 hit point and only then rounded to
+//    fp32.  The shadow origin p = hit + n*1e-6 therefore sits on the correct side of its own
+//    surface exactly as in the reference, with no self-intersection heuristics.
+//  * The shadow walk of the reference (compute_shadow_transmission_batch, ray_tracer.py:247-293:
+//    nearest hit, multiply by the blocker's transparency, step past it, repeat) visits, in order,
+//    every surface crossing of the segment; its result is the product of the transparencies of
+//    all crossings.  The fast kernel forms that product directly from both roots of every
+//    primitive: crossing parameter t' measured from p is in range iff 2e-6 < t' < dist (the
+//    reference starts at p + dir*1e-6, accepts t > 1e-6 and stops at dist - 1e-6).
+//    Differences to the walk (early stop below 1e-6, 20-step cap, crossings closer than 1e-6 to
+//    each other) are below the fp32 tolerance.
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mkf(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 tof(d3 v) { return mkf((float)v.x, (float)v.y, (float)v.z); }
+__device__ __forceinline__ float dotf(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 crossf(f3 a, f3 b) {
+  return mkf(fmaf(a.y, b.z, -a.z * b.y), fmaf(a.z, b.x, -a.x * b.z), fmaf(a.x, b.y, -a.y * b.x));
+}
+__device__ __forceinline__ f3 scalef(f3 a, float s) { return mkf(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 normalize_clamped(f3 a) {   // v / max(|v|, 1e-6)
+  float n2 = dotf(a, a);
+  float inv = n2 > 1e-12f ? __frsqrt_rn(n2) : 1e6f;
+  return scalef(a, inv);
+}
+
+constexpr float T_LO = 2e-6f;   // see header: 1e-6 origin shift + 1e-6 hit threshold
+
+template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                      RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
+                                                      float* __restrict__ fb, int n_chunks) {
+  __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  uint32_t count = C->n_hits[level];
+  if (count > fp.queue_cap) count = fp.queue_cap;
+  const uint32_t lane = __lane_id();
+  const int n_sh = fp.n_shadow;
+  const int n_cells = n_sh > 1 ? n_sh * n_sh : 1;
+  const float inv_cells = 1.0f / (float)n_cells;
+  for (;;) {
+    uint32_t base = grab64(&C->work_shade[level]);
+    if (base >= count) break;
+    uint32_t h = base + lane;
+    bool active = h < count;
+    RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0);
+    const double* mat = sc.mats;
+    r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
+    if (active) {
+      HitRec hr = hits[h];
+      r = load_ray(level, hr.slot, cam, fp.rs, q);
+      const Prim& pr = P[hr.prim];
+      const double t = hr.t;
+      n = prim_normal(pr, r.o, r.d, t);
+      hp = mk3(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);
+      mat = sc.mats + MAT_STRIDE * pr.mat;
+      const f3 v = normalize_clamped(mkf((float)(r.o.x - hp.x), (float)(r.o.y - hp.y), (float)(r.o.z - hp.z)));
+      const f3 nf = tof(n);
+      const uint32_t gpix = global_pixel(fp.rs, r.lp);
+      const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);
+      float dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+      for (int li = 0; li < sc.nL; ++li) {
+        const double* lg = sc.lights + LIGHT_STRIDE * li;
+        const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
+        // light-facing basis (ray_tracer.py:198-213)
+        const f3 ld = scalef(tl, __frsqrt_rn(dotf(tl, tl)));
+        const f3 ref = (fabsf(ld.x) >= 0.9f) ? mkf(0, 1, 0) : mkf(1, 0, 0);
+        const f3 right = normalize_clamped(crossf(ld, ref));
+        const f3 up = normalize_clamped(crossf(right, ld));
+        const float radius = (float)lg[8];
+        const float cell = radius / (float)(n_sh > 1 ? n_sh : 1);
+        const float half = -0.5f * radius;
+        const float cell16 = cell * (1.0f / 65536.0f);
+        const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+        float total = 0.0f;
+        for (int c = 0; c < n_chunks; ++c) {
+          float dx[CH], dy[CH], dz[CH], md[CH], tr[CH];
+          float ix[HAS_BOX ? CH : 1], iy[HAS_BOX ? CH : 1], iz[HAS_BOX ? CH : 1];
+#pragma unroll
+          for (int s = 0; s < CH; ++s) {
+            const int cellidx = c * CH + s;
+            f3 ts = tl;
+            if (n_sh > 1) {                                   // ray_tracer.py:219-235
+              const int i = cellidx / n_sh, j = cellidx - i * n_sh;
+              const uint32_t bits = jit_cell_bits(key, (uint32_t)cellidx);
+              const float oi = fmaf((float)(bits >> 16), cell16, fmaf(cell, (float)i, half));
+              const float oj = fmaf((float)(bits & 0xFFFFu), cell16, fmaf(cell, (float)j, half));
+              ts = mkf(fmaf(oj, up.x, fmaf(oi, right.x, tl.x)), fmaf(oj, up.y, fmaf(oi, right.y, tl.y)),
+                       fmaf(oj, up.z, fmaf(oi, right.z, tl.z)));
+            }
+            const float d2 = dotf(ts, ts);
+            const float rinv = __frsqrt_rn(d2);
+            dx[s] = ts.x * rinv; dy[s] = ts.y * rinv; dz[s] = ts.z * rinv;
+            md[s] = d2 * rinv;
+            tr[s] = (cellidx < n_cells) ? 1.0f : 0.0f;
+            if (HAS_BOX) { ix[s] = __frcp_rn(dx[s]); iy[s] = __frcp_rn(dy[s]); iz[s] = __frcp_rn(dz[s]); }
+          }
+          int k = 0;
+          for (int e = sc.nS; k < e; ++k) {                   // spheres: sphere.py:49-71
+            const Prim& s_ = P[k];
+            const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
+            const float cc = (float)(((ocx * ocx + ocy * ocy) + ocz * ocz) - s_.a[4]);
+            const f3 oc = mkf((float)ocx, (float)ocy, (float)ocz);
+            const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+              const float b = fmaf(oc.z, dz[s], fmaf(oc.y, dy[s], oc.x * dx[s]));   // oc.d  (a = d.d = 1)
+              const float disc = fmaf(b, b, -cc);
+              const float sq = __fsqrt_rn(fmaxf(disc, 0.0f));
+              const float t1 = -b - sq, t2 = sq - b;
+              const bool ok = disc >= 0.0f;
+              const bool in1 = ok && t1 > T_LO && t1 < md[s];
+              const bool in2 = ok && t2 > T_LO && t2 < md[s];
+              if (OPAQUE) { if (in1 || in2) tr[s] = 0.0f; }
+              else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+            }
+          }
+          for (int e = sc.nS + sc.nP; k < e; ++k) {           // planes: infinite_plane.py:30-42
+            const Prim& s_ = P[k];
+            const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
+            const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+            const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+              const float den = fmaf(N.z, dz[s], fmaf(N.y, dy[s], N.x * dx[s]));
+              const float t1 = num * __frcp_rn(den);
+              const bool in1 = fabsf(den) >= 1e-10f && t1 > T_LO && t1 < md[s];
+              if (OPAQUE) { if (in1) tr[s] = 0.0f; }
+              else tr[s] *= in1 ? tau : 1.0f;
+            }
+          }
+          if (HAS_BOX) {
+            for (int e = sc.nS + sc.nP + sc.nB; k < e; ++k) { // boxes: cube.py:76-107 (slab roots)
+              const Prim& s_ = P[k];
+              const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
+              const f3 hi = mkf((float)(s_.a[3] - p.x), (float)(s_.a[4] - p.y), (float)(s_.a[5] - p.z));
+              const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+#pragma unroll
+              for (int s = 0; s < CH; ++s) {
+                const float ax = lo.x * ix[s], bx = hi.x * ix[s];
+                const float ay = lo.y * iy[s], by = hi.y * iy[s];
+                const float az = lo.z * iz[s], bz = hi.z * iz[s];
+                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                const bool ok = tn <= tf;
+                const bool in1 = ok && tn > T_LO && tn < md[s];
+                const bool in2 = ok && tf > T_LO && tf < md[s];
+                if (OPAQUE) { if (in1 || in2) tr[s] = 0.0f; }
+                else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+              }
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < CH; ++s) total += tr[s];
+        }
+        const float T = total * inv_cells;
+        const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                       // ray_tracer.py:543
+        const f3 l = normalize_clamped(mkf((float)(lg[0] - hp.x), (float)(lg[1] - hp.y), (float)(lg[2] - hp.z)));
+        const float ndl = fmaxf(dotf(nf, l), 0.0f);
+        const float s1 = I * ndl;
+        dif[0] = fmaf((float)mat[0] * (float)lg[3], s1, dif[0]);
+        dif[1] = fmaf((float)mat[1] * (float)lg[4], s1, dif[1]);
+        dif[2] = fmaf((float)mat[2] * (float)lg[5], s1, dif[2]);
+        const float dn = -dotf(l, nf);                                                    // (-l).n
+        const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -l.x), fmaf(-2.0f * dn, nf.y, -l.y), fmaf(-2.0f * dn, nf.z, -l.z));
+        const float rdv = fmaxf(dotf(rf, v), 0.0f);
+        const float shin = (float)mat[9];
+        const float pw = (shin == 0.0f) ? 1.0f : (rdv > 0.0f ? powf(rdv, shin) : 0.0f);   // np.power(0, 0) == 1
+        const float s2 = I * pw * (float)lg[6];
+        spc[0] = fmaf((float)mat[3] * (float)lg[3], s2, spc[0]);
+        spc[1] = fmaf((float)mat[4] * (float)lg[4], s2, spc[1]);
+        spc[2] = fmaf((float)mat[5] * (float)lg[5], s2, spc[2]);
+      }
+      const float one_m = 1.0f - (float)mat[10];
+      atomicAdd(&fb[3 * (size_t)r.lp + 0], (float)r.w.x * ((dif[0] + spc[0]) * one_m));
+      atomicAdd(&fb[3 * (size_t)r.lp + 1], (float)r.w.y * ((dif[1] + spc[1]) * one_m));
+      atomicAdd(&fb[3 * (size_t)r.lp + 2], (float)r.w.z * ((dif[2] + spc[2]) * one_m));
+    }
+    spawn_children(active, level, fp, mat, r, hp, n, nq, C);
+  }
+}
+
+// Chunk size for an n x n grid: the candidate with the least padding, larger preferred.
+static inline int pick_chunk(int n_cells) {
+  const int cand[] = {25, 16, 9, 4, 1};
+  int best = 1, best_waste = 1 << 30;
+  for (int c : cand) {
+    int chunks = (n_cells + c - 1) / c;
+    int waste = chunks * c - n_cells;
+    if (waste < best_waste) { best_waste = waste; best = c; }
+  }
+  return best;
+}
+
+template <int CH>
+static void launch_shade_fast_ch(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
+                                 RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                                 hipStream_t st, int n_chunks) {
+  const bool lds = ds.n <= LDS_PRIMS, box = ds.nB > 0;
+#define RT_LAUNCH(OP, BX, LD)                                                                                     \
+  hipLaunchKernelGGL((k_shade_fast<CH, OP, BX, LD>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, \
+                     hits, C, fb, n_chunks)
+  if (opaque) {
+    if (!box && lds) RT_LAUNCH(true, false, true);
+    else if (lds) RT_LAUNCH(true, true, true);
+    else RT_LAUNCH(true, true, false);
+  } else {
+    if (!box && lds) RT_LAUNCH(false, false, true);
+    else if (lds) RT_LAUNCH(false, true, true);
+    else RT_LAUNCH(false, true, false);
+  }
+#undef RT_LAUNCH
+}
+
+static void launch_shade_fast(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
+                              RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                              hipStream_t st) {
+  const int n_cells = fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1;
+  const int ch = pick_chunk(n_cells);
+  const int n_chunks = (n_cells + ch - 1) / ch;
+  switch (ch) {
+    case 25: launch_shade_fast_ch<25>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+    case 16: launch_shade_fast_ch<16>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+    case 9: launch_shade_fast_ch<9>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+    case 4: launch_shade_fast_ch<4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+    default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+  }
+}
+
+}  // namespace rt

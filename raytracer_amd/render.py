@@ -1,0 +1,174 @@
+"""Host side of the drop-in boundary: `render_hip` has the signature and return value of the
+reference's `render_vectorized` (ray_tracer.py:437-604) and runs it on the GPU through the C-ABI
+of librt_hip.so.  Also the GPU-backed counterparts of the reference helpers that unit tests pin:
+`nearest_hit` (find_nearest_intersection_batch, ray_tracer.py:112-127), `shadow_transmission`
+(compute_shadow_transmission_batch, :247-293) and `camera_rays` (camera.py:75-104).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from .jitter import as_jitter
+from .packing import PackedScene, pack_camera, pack_scene, pack_surfaces, rows_in_part
+
+_PRECISION = {"fp64": _lib.RT_FP64, "fp32": _lib.RT_FP32, "f64": _lib.RT_FP64, "f32": _lib.RT_FP32}
+_OUT = {"f64": (_lib.RT_OUT_F64, np.float64), "f32": (_lib.RT_OUT_F32, np.float32), "u8": (_lib.RT_OUT_U8, np.uint8)}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GpuScene:
+    """Device copy of a packed scene (rt_scene handle).  Reusable across frames; owns a HIP stream
+    and the render workspace.  Use as a context manager or call close()."""
+
+    def __init__(self, packed: PackedScene, device: int = 0):
+        self._lib = _lib.load()
+        self.packed = packed
+        self.device = int(device)
+        d = _lib.SceneDesc()
+        d.n_surfaces = len(packed.surf_type); d.surf_type = _ptr(packed.surf_type)
+        d.surf_data = _ptr(packed.surf_data); d.surf_material = _ptr(packed.surf_material)
+        d.n_materials = len(packed.materials); d.materials = _ptr(packed.materials)
+        d.n_lights = len(packed.lights); d.lights = _ptr(packed.lights)
+        d.background[:] = list(packed.background)
+        h = C.c_void_p()
+        _lib.check(self._lib.rt_scene_create(C.byref(d), self.device, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_objects(cls, materials, surfaces, lights, background_color, device=0):
+        return cls(pack_scene(materials, surfaces, lights, background_color), device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._lib.rt_scene_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def sync(self):
+        _lib.check(self._lib.rt_sync(self._h))
+
+    # -- the hot path -------------------------------------------------------------------------
+    def render(self, camera, width, height, n_shadow, max_depth, *, precision="fp64", jitter=None,
+               block_rows=1, part=0, n_parts=1, out_format=None, out_ptr=None, flags=0, stats=None):
+        """Render a row set.  With `out_ptr` (a device pointer, e.g. torch_tensor.data_ptr()) the
+        result stays on the GPU; otherwise a NumPy array (rows, width, 3) is returned."""
+        jit = as_jitter(jitter)
+        if camera.forward is None:
+            camera.setup(width / height)
+        cam = _lib.CameraDesc()
+        v = pack_camera(camera)
+        cam.pos[:] = v[0:3]; cam.forward[:] = v[3:6]; cam.right[:] = v[6:9]; cam.up[:] = v[9:12]
+        cam.screen_distance, cam.screen_width, cam.screen_height = v[12], v[13], v[14]
+        prec = _PRECISION[precision]
+        if out_format is None:
+            out_format = "f64" if prec == _lib.RT_FP64 else "f32"
+        fmt, dtype = _OUT[out_format]
+        fr = _lib.Frame(int(width), int(height), int(block_rows), int(part), int(n_parts), int(n_shadow),
+                        int(max_depth), prec, int(jit.mode), jit.seed & 0xFFFFFFFF, fmt, int(flags))
+        st = stats if stats is not None else _lib.Stats()
+        if out_ptr is not None:
+            _lib.check(self._lib.rt_render(self._h, C.byref(cam), C.byref(fr), C.c_void_p(out_ptr), 1, C.byref(st)))
+            return None
+        rows = len(rows_in_part(height, block_rows, part, n_parts))
+        out = np.empty((rows, width, 3), dtype=dtype)
+        _lib.check(self._lib.rt_render(self._h, C.byref(cam), C.byref(fr), _ptr(out), 0, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out
+
+    # -- helpers pinned by unit tests ---------------------------------------------------------
+    def nearest_hit(self, origins, dirs):
+        o, d = _rays(origins, dirs)
+        t = np.empty(len(o)); idx = np.empty(len(o), dtype=np.int32); n = np.empty((len(o), 3))
+        _lib.check(self._lib.rt_nearest_hit(self._h, _ptr(o), _ptr(d), len(o), _ptr(t), _ptr(idx), _ptr(n)))
+        return t, idx, n
+
+    def shadow_transmission(self, origins, dirs, max_distances):
+        o, d = _rays(origins, dirs)
+        md = np.ascontiguousarray(max_distances, dtype=np.float64)
+        if md.shape != (len(o),):
+            raise ValueError("max_distances must have one entry per ray")
+        out = np.empty(len(o))
+        _lib.check(self._lib.rt_shadow_transmission(self._h, _ptr(o), _ptr(d), _ptr(md), len(o), _ptr(out)))
+        return out
+
+
+def _rays(origins, dirs):
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    if o.shape != d.shape:
+        raise ValueError(f"origins {o.shape} and directions {d.shape} differ")
+    return o, d
+
+
+def render_hip(camera, scene_settings, materials, surfaces, lights, width, height, *,
+               precision="fp64", jitter=None, device=0, stats=None, verbose=True):
+    """Drop-in for the reference's render_vectorized: returns (height, width, 3) float64 unclipped
+    linear radiance and, like the reference, calls camera.setup(width / height) first.
+
+    Keyword-only extras: precision "fp64" (1e-9 relative parity) or "fp32" (fast mode, <= 1/255 per
+    8-bit channel); jitter = int seed | ("pixel", seed) | ("numpy", seed); stats = dict to fill.
+    """
+    t0 = time.time()
+    camera.setup(width / height)
+    n_shadow = int(scene_settings.root_number_shadow_rays)
+    max_depth = int(scene_settings.max_recursions)
+    if verbose:
+        print(f"Max depth: {max_depth}, Shadow rays: {n_shadow}x{n_shadow}={n_shadow * n_shadow} per light")
+        print(f"HIP rendering {width}x{height} = {width * height} rays ({precision})...")
+    with GpuScene.from_objects(materials, surfaces, lights, scene_settings.background_color, device) as gs:
+        img = gs.render(camera, width, height, n_shadow, max_depth, precision=precision, jitter=jitter)
+        st = gs.last_stats
+    if stats is not None:
+        stats.update(st)
+    if verbose:
+        print(f"HIP rendering complete in {time.time() - t0:.3f}s ({st['rays']} total rays, "
+              f"{st['shadow_rays']} shadow rays)")
+    return np.ascontiguousarray(img, dtype=np.float64)
+
+
+render_vectorized = render_hip   # same name as the reference entry point
+
+
+def nearest_hit(surfaces, origins, dirs, device=0):
+    st, sd, sm = pack_surfaces(surfaces)
+    ps = PackedScene(st, sd, np.zeros(len(surfaces), dtype=np.int32), np.zeros((1, 11)), np.zeros((0, 9)), np.zeros(3))
+    with GpuScene(ps, device) as gs:
+        return gs.nearest_hit(origins, dirs)
+
+
+def shadow_transmission(materials, surfaces, origins, dirs, max_distances, device=0):
+    with GpuScene.from_objects(materials, surfaces, [], np.zeros(3), device) as gs:
+        return gs.shadow_transmission(origins, dirs, max_distances)
+
+
+def camera_rays(camera, width, height, y0=0, y1=None, device=0):
+    y1 = height if y1 is None else y1
+    lib = _lib.load()
+    ps = PackedScene(np.zeros(0, np.int32), np.zeros((0, 8)), np.zeros(0, np.int32), np.zeros((1, 11)),
+                     np.zeros((0, 9)), np.zeros(3))
+    cam = _lib.CameraDesc()
+    v = pack_camera(camera)
+    cam.pos[:] = v[0:3]; cam.forward[:] = v[3:6]; cam.right[:] = v[6:9]; cam.up[:] = v[9:12]
+    cam.screen_distance, cam.screen_width, cam.screen_height = v[12], v[13], v[14]
+    n = (y1 - y0) * width
+    o = np.empty((n, 3)); d = np.empty((n, 3))
+    with GpuScene(ps, device) as gs:
+        _lib.check(lib.rt_camera_rays(gs._h, C.byref(cam), int(width), int(height), int(y0), int(y1), _ptr(o), _ptr(d)))
+    return o, d
