@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: frames of BASELINE.json's headline workload.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one frame: every rank renders its interleaved row blocks of the frame into device memory
+(the scene is already resident in HBM) and, for N > 1, the tiles are gathered to rank 0 over RCCL.
+The frame is fixed as N grows (strong scaling).  Rank 0 prints ONE JSON line.
+
+metric/value: Mrays/s, rays = radiance rays + shadow rays of the frame, whole job.
+roofline: the dominant kernel (k_shade_fast / k_shade_exact) — algorithmic flops of its launches
+  (raytracer_amd/flops.py) / their summed duration, measured with HIP events on the
+  stream the kernels run on (rt_stats, RT_FLAG_TIMING) during the timed steps.  The bound is the
+  vector ALU (no MFMA-shaped work, HBM traffic is one framebuffer write), peak = 157.3 TFLOP/s fp32
+  / 78.6 fp64 (MI355X_MICROARCH.md chip table).
+cpu_baseline: the C oracle (oracle/rt_oracle.c, a port of the reference's algorithm) timed on this
+  box's host cores on a bounded sample of the same workload; rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene file, W, H, n_shadow, max_depth, precision, description)
+    "pool4k": ("pool.txt", 3840, 2160, 5, 3, "fp32", "pool.txt 3840x2160, 5x5 shadow rays, depth 3, fp32 (BASELINE configs[2])"),
+    "original1080": ("original.txt", 1920, 1080, None, None, "fp64", "original.txt 1920x1080, file settings (3x3, depth 5), fp64 (BASELINE configs[1])"),
+    "pool8k": ("pool.txt", 7680, 4320, 8, 6, "fp32", "pool.txt 7680x4320, 8x8 shadow rays, depth 6, fp32 (BASELINE configs[4])"),
+    "synth4k": ("synth:4096:512", 3840, 2160, 3, 3, "fp32", "synthetic 4096 spheres + 512 boxes 3840x2160, 3x3 shadow rays, depth 3, fp32 (BASELINE configs[3])"),
+    "pool500": ("pool.txt", 500, 500, None, None, "fp64", "pool.txt 500x500 file settings, fp64 (BASELINE configs[0] shape)"),
+}
+PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}
+
+
+def load_workload(name):
+    from raytracer_amd import load_scene, parse_scene_text, separate_objects
+    from raytracer_amd.synth import synthetic_scene_text
+    scene, W, H, n, depth, precision, desc = WORKLOADS[name]
+    if scene.startswith("synth:"):
+        _, ns, nb = scene.split(":")
+        cam, st, objs = parse_scene_text(synthetic_scene_text(int(ns), int(nb), shadow_rays=n, max_recursions=depth))
+        mats, surfs, lights = separate_objects(objs)
+    else:
+        cam, st, mats, surfs, lights = load_scene(os.path.join(ROOT, "scenes", scene), n, depth)
+    return cam, st, mats, surfs, lights, W, H, precision, desc
+
+
+def cpu_baseline(name, gs, cam, st, mats, surfs, lights, W, H, precision):
+    """Time the oracle on a bounded sample (a quarter-resolution frame of the same workload) and
+    check the GPU render of the same sample against it."""
+    import numpy as np
+    from oracle import oracle
+    from raytracer_amd.image import quantize_u8
+    threads = min(16, os.cpu_count() or 1)
+    oracle.build()
+    oracle.set_threads(threads)
+    div = 4 if name != "synth4k" else 40
+    w, h = max(W // div, 16), max(H // div, 9)
+    cam.setup(w / h)
+    t0 = time.perf_counter()
+    ref, ost = oracle.render(cam, st, mats, surfs, lights, w, h, jitter=("pixel", 1234), return_stats=True)
+    dt = time.perf_counter() - t0
+    rays = ost["rays"] + ost["shadow_rays"]
+    img = gs.render(cam, w, h, st.root_number_shadow_rays, st.max_recursions, precision=precision, jitter=1234)
+    cam.setup(W / H)
+    d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+    rel = float((np.abs(img - ref) / np.maximum(np.abs(ref), 1e-12)).max())
+    base = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{WORKLOADS[name][0]} {w}x{h} (1/{div * div} of the frame's pixels), same shadow rays/depth, "
+                      f"1 frame, {rays} rays in {dt:.2f} s, C oracle with OpenMP"}
+    parity = {"sample": f"{w}x{h}", "max_8bit_diff": int(d8.max()), "channels_gt_1_level": int((d8 > 1).sum()),
+              "channels": int(d8.size), "max_rel_err": rel}
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pool4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--block-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import _lib
+    from raytracer_amd.dist import RowTiling, cache_row_indices, gather_tiles
+    from raytracer_amd.flops import shade_kernel_flops, flops_per_query
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
+    n_shadow, max_depth = int(st.root_number_shadow_rays), int(st.max_recursions)
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    gs = GpuScene(packed, device=local_rank)
+    gs.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels, gather and events share one stream
+
+    tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
+    dtype = torch.float32 if precision == "fp32" else torch.float64
+    tile = torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev)
+    frame = torch.empty((H, W, 3), dtype=dtype, device=dev) if (world > 1 and rank == 0) else None
+    scratch = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    flags = _lib.RT_FLAG_ASYNC | (0 if args.no_timing else _lib.RT_FLAG_TIMING)
+
+    def step(stats):
+        gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                  part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
+        if world > 1:
+            gather_tiles(tile, tiling, rank, out=frame, scratch=scratch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(_lib.Stats())
+    gs.sync()
+    all_stats = [_lib.Stats() for _ in range(args.steps)]
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in all_stats:
+        step(s)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    gs.sync()   # folds counters / event timings into the rt_stats of the timed steps
+
+    # whole-job numbers: max time over ranks, rays summed over ranks
+    last = all_stats[-1]
+    my = torch.tensor([elapsed, float(last.rays), float(last.hits), float(last.shadow_rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = my[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = my[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); rays, hits, shadow = (float(x) for x in sums)
+    else:
+        rays, hits, shadow = float(last.rays), float(last.hits), float(last.shadow_rays)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_rays = rays + shadow
+        value = total_rays / (ms_per_step * 1e-3) / 1e6
+        n_sph, n_pln, n_box = packed.counts
+        # dominant kernel on this rank: shade launches of the timed steps
+        shade_ms = sum(s.shade_ms for s in all_stats) / args.steps
+        trace_ms = sum(s.trace_ms for s in all_stats) / args.steps
+        launches = max(last.shade_launches, 1)
+        seg = max(int(last.segments), 0)
+        flops_frame = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
+                                         hits=int(last.hits), segments=seg)
+        roofline = None
+        if shade_ms > 0:
+            achieved = flops_frame / (shade_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "valu", "kernel": "k_shade_fast" if precision == "fp32" else "k_shade_exact",
+                        "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
+                        "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
+                        "launches_per_step": launches, "shade_ms_per_step": round(shade_ms, 4),
+                        "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
+        out = {
+            "metric": "Mrays/s incl. shadow+secondary rays, pool.txt 4K" if args.workload == "pool4k"
+                      else f"Mrays/s incl. shadow+secondary rays, {args.workload}",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if precision == "fp32" else "f64",
+            "data": "reference scene values (scenes/pool.txt etc. in-repo), pixel-keyed jitter seed 1234",
+            "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
+                       "shadow_rays": int(shadow), "row_blocks": args.block_rows,
+                       "parallelism": f"row-tiled x{world}" + (", RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline(args.workload, gs, cam, st, mats, surfs, lights, W, H, precision)
+            out["cpu_baseline"] = base
+            out["parity_check"] = parity
+        print(json.dumps(out), flush=True)
+
+    gs.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -17,6 +18,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
+#include "rt_shade_small.hpp"
 
 using namespace rt;
 
@@ -66,6 +68,7 @@ struct rt_scene {
   DevScene ds{};
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
   bool all_opaque = true;
+  bool force_general = false;   // RT_FORCE_GENERAL=1: skip the small-scene kernel (testing)
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
@@ -161,6 +164,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
+  if (const char* e = getenv("RT_FORCE_GENERAL")) s->force_general = e[0] == '1';
   *out = s;
   return RT_OK;
 }
@@ -176,7 +180,10 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
   for (hipEvent_t e : s->event_pool) hipEventDestroy(e);
-  for (PendingFrame& pf : s->pending) for (EventPair& ep : pf.events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+  for (PendingFrame& pf : s->pending) {   // frames never synced: their rt_stats are not written
+    for (EventPair& ep : pf.events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    if (pf.h_counters) hipHostFree(pf.h_counters);
+  }
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -308,9 +315,14 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
   { Timed t(s, pf, 2); hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(256), 0, s->stream, s->d_counters, P); }
   for (int level = 0; level <= fp.max_depth; ++level) {
     RayQueue cur = q[level & 1], nxt = q[(level + 1) & 1];
-    int tgrid = grid;
-    if (level == 0) tgrid = (int)std::min<size_t>((size_t)grid, ((size_t)P + BLOCK - 1) / BLOCK);
+    int tgrid = grid;       // trace: one workgroup per TRACE_CHUNK rays, grid-stride beyond that
+    int sgrid = grid;       // shade
+    if (level == 0) {
+      tgrid = (int)std::min<size_t>((size_t)grid * 4, ((size_t)P + TRACE_CHUNK - 1) / TRACE_CHUNK);
+      sgrid = (int)std::min<size_t>((size_t)grid, ((size_t)P + BLOCK - 1) / BLOCK);
+    }
     if (tgrid < 1) tgrid = 1;
+    if (sgrid < 1) sgrid = 1;
     {
       Timed t(s, pf, 0);
       if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
@@ -319,10 +331,12 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
     {
       Timed t(s, pf, 1);
       if (fr->precision == RT_FP64) {
-        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
-        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
+        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
+        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
       } else {
-        launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, tgrid, s->stream);
+        // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
+        if (s->force_general || !launch_shade_small(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream))
+          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
       }
     }
   }

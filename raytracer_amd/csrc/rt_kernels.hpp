@@ -80,6 +80,16 @@ __device__ __forceinline__ void fb_add(FB* fb, uint32_t lp, double r, double g, 
   atomicAdd(&fb[3 * (size_t)lp + 2], (FB)b);
 }
 
+// Level 0: the hit's pixel has no other contribution yet (0 + w*c == w*c exactly) -> plain store.
+template <typename FB>
+__device__ __forceinline__ void fb_put(FB* fb, bool first, uint32_t lp, double r, double g, double b) {
+  if (first) {
+    fb[3 * (size_t)lp + 0] = (FB)r; fb[3 * (size_t)lp + 1] = (FB)g; fb[3 * (size_t)lp + 2] = (FB)b;
+  } else {
+    fb_add(fb, lp, r, g, b);
+  }
+}
+
 struct RayIn { d3 o, d, w; uint32_t lp; };
 
 __device__ __forceinline__ RayIn load_ray(int level, uint32_t slot, const DevCamera& cam, const RowSet& rs, const RayQueue& q) {
@@ -102,40 +112,62 @@ __device__ __forceinline__ RayIn load_ray(int level, uint32_t slot, const DevCam
 // ------------------------------------------------------------------------------- k_trace -------
 // Primary-ray generation (level 0) / queue read, brute-force nearest hit, miss -> background,
 // hit compaction.  ray_tracer.py:491-515 and camera.py:46-73.
+//
+// A workgroup owns chunks of TRACE_CHUNK consecutive rays.  Hits are compacted into an LDS staging
+// buffer with wave-aggregated LDS atomics (ballot + mbcnt prefix), then the whole chunk is appended
+// to the global hit queue with ONE global atomic and coalesced 16-byte stores.  (A single device
+// counter sustains only ~88 atomics/us on MI355X, so per-wave appends would serialise a 4K frame's
+// 130k waves into >1 ms.)
+constexpr int TRACE_CHUNK = 1024;
+
 template <typename FB, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                  HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  __shared__ HitRec s_hits[TRACE_CHUNK];
+  __shared__ uint32_t s_count, s_base;
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   uint32_t count = C->n_rays[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
-  const uint32_t lane = __lane_id();
-  for (;;) {
-    uint32_t base = grab64(&C->work_trace[level]);
-    if (base >= count) break;
-    uint32_t slot = base + lane;
-    bool active = slot < count;
-    bool hit = false;
-    int k = -1; double t = RT_INF;
-    if (active) {
-      RayIn r = load_ray(level, slot, cam, fp.rs, q);
-      t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k);
-      hit = k >= 0;
-      if (level == 0) {
-        // every pixel has exactly one level-0 ray: plain store initialises the framebuffer
-        // (0 + 1*bg == bg exactly; hit pixels start from 0 and are added to by the shade kernels)
-        fb[3 * (size_t)r.lp + 0] = hit ? (FB)0 : (FB)sc.bg[0];
-        fb[3 * (size_t)r.lp + 1] = hit ? (FB)0 : (FB)sc.bg[1];
-        fb[3 * (size_t)r.lp + 2] = hit ? (FB)0 : (FB)sc.bg[2];
-      } else if (!hit) {
-        fb_add(fb, r.lp, r.w.x * sc.bg[0], r.w.y * sc.bg[1], r.w.z * sc.bg[2]);   // :500-502
+  const uint32_t n_chunks = (count + TRACE_CHUNK - 1) / TRACE_CHUNK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < TRACE_CHUNK / BLOCK; ++it) {
+      const uint32_t slot = chunk * TRACE_CHUNK + it * BLOCK + threadIdx.x;
+      const bool active = slot < count;
+      bool hit = false;
+      int k = -1; double t = RT_INF;
+      if (active) {
+        RayIn r = load_ray(level, slot, cam, fp.rs, q);
+        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k);
+        hit = k >= 0;
+        if (level == 0) {
+          // every pixel has exactly one level-0 ray: a plain store initialises the framebuffer
+          // (0 + 1*bg == bg exactly); hit pixels are stored by the level-0 shade kernel
+          if (!hit) {
+            fb[3 * (size_t)r.lp + 0] = (FB)sc.bg[0];
+            fb[3 * (size_t)r.lp + 1] = (FB)sc.bg[1];
+            fb[3 * (size_t)r.lp + 2] = (FB)sc.bg[2];
+          }
+        } else if (!hit) {
+          fb_add(fb, r.lp, r.w.x * sc.bg[0], r.w.y * sc.bg[1], r.w.z * sc.bg[2]);   // :500-502
+        }
       }
+      const uint32_t ls = wave_append(&s_count, hit);   // LDS atomic, one per wave
+      if (hit) { HitRec h; h.slot = slot; h.prim = k; h.t = t; s_hits[ls] = h; }
     }
-    uint32_t hslot = wave_append(&C->n_hits[level], hit);
-    if (hit) {
-      if (hslot < fp.queue_cap) { HitRec h; h.slot = slot; h.prim = k; h.t = t; hits[hslot] = h; }
+    __syncthreads();
+    const uint32_t n_local = s_count;
+    if (threadIdx.x == 0) s_base = n_local ? atomicAdd(&C->n_hits[level], n_local) : 0u;
+    __syncthreads();
+    const uint32_t gbase = s_base;
+    for (uint32_t i = threadIdx.x; i < n_local; i += BLOCK) {
+      if (gbase + i < fp.queue_cap) hits[gbase + i] = s_hits[i];
       else C->overflow = 1u;
     }
+    __syncthreads();
   }
 }
 
@@ -262,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
         spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
       }
       double one_m = 1 - mat[10];                                                      // :562-563
-      fb_add(fb, r.lp, r.w.x * ((dif[0] + spc[0]) * one_m), r.w.y * ((dif[1] + spc[1]) * one_m),
+      fb_put(fb, level == 0, r.lp, r.w.x * ((dif[0] + spc[0]) * one_m), r.w.y * ((dif[1] + spc[1]) * one_m),
              r.w.z * ((dif[2] + spc[2]) * one_m));
       atomicAdd(&C->queries, (unsigned long long)queries);
     }

@@ -1,0 +1,74 @@
+"""Multi-GPU rendering: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The image is cut into blocks of `block_rows` rows dealt round-robin to the ranks (interleaved so
+that cheap sky rows and expensive sphere rows are spread evenly — SURVEY.md §5.7).  With
+pixel-keyed jitter every pixel is independent, so the ranks exchange nothing while rendering; the
+only communication is one gather of the finished tiles to rank 0 per frame (RCCL send/recv over
+xGMI under torch.distributed.gather), after which rank 0 scatters the rows into place.
+
+The renderer is injected as a callable so the tiling + gather logic can be tested on CPU with the
+gloo backend (tests/test_dist_gloo.py) and driven by the HIP renderer in production (bench.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .packing import rows_in_part
+
+
+class RowTiling:
+    """Row-set bookkeeping shared by all ranks."""
+
+    def __init__(self, height, width, world_size, block_rows=16):
+        self.height, self.width, self.world_size, self.block_rows = int(height), int(width), int(world_size), int(block_rows)
+        self.rows = [rows_in_part(self.height, self.block_rows, p, self.world_size) for p in range(self.world_size)]
+        self.max_rows = max(len(r) for r in self.rows)
+
+    def n_rows(self, part):
+        return len(self.rows[part])
+
+
+def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, scratch=None):
+    """Gather per-rank tiles (torch tensors [max_rows, W, C], rows beyond the rank's own count are
+    padding) to `dst` and reassemble the frame [H, W, C] there.  Returns the frame on `dst`,
+    None elsewhere.  `out` / `scratch` let the caller reuse buffers across frames."""
+    import torch
+    import torch.distributed as dist
+
+    world = tiling.world_size
+    if world == 1:
+        frame = tile[: tiling.n_rows(0)]
+        if out is not None:
+            out.copy_(frame)
+            return out
+        return frame
+    assert tile.shape[0] == tiling.max_rows and tile.is_contiguous()
+    if rank == dst:
+        if scratch is None:
+            scratch = [torch.empty_like(tile) for _ in range(world)]
+        dist.gather(tile, gather_list=scratch, dst=dst, group=group)
+        if out is None:
+            out = torch.empty((tiling.height, tiling.width) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
+        for p in range(world):
+            idx = torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long) if not hasattr(tiling, "_idx") else None
+            if idx is None:
+                idx = tiling._idx[p]
+            out.index_copy_(0, idx, scratch[p][: tiling.n_rows(p)])
+        return out
+    dist.gather(tile, gather_list=None, dst=dst, group=group)
+    return None
+
+
+def cache_row_indices(tiling: RowTiling, device):
+    """Put the per-part row index tensors on `device` once (avoids a host->device copy per frame)."""
+    import torch
+    tiling._idx = [torch.as_tensor(r, device=device, dtype=torch.long) for r in tiling.rows]
+    return tiling
+
+
+def render_distributed(render_rows, tiling: RowTiling, rank, *, new_tile, dst=0, group=None, out=None, scratch=None):
+    """One frame: `render_rows(part, tile)` fills this rank's tile (a [max_rows, W, 3] tensor made
+    by `new_tile()` or reused), then the tiles are gathered to `dst`."""
+    tile = new_tile()
+    render_rows(rank, tile)
+    return gather_tiles(tile, tiling, rank, dst=dst, group=group, out=out, scratch=scratch)

@@ -40,6 +40,7 @@ class GpuScene:
         h = C.c_void_p()
         _lib.check(self._lib.rt_scene_create(C.byref(d), self.device, C.byref(h)))
         self._h = h
+        self._keepalive = []   # rt_stats of async frames: the library writes them at the next sync
 
     @classmethod
     def from_objects(cls, materials, surfaces, lights, background_color, device=0):
@@ -47,8 +48,9 @@ class GpuScene:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.rt_scene_destroy(self._h)
+            self._lib.rt_scene_destroy(self._h)   # synchronises the stream first
             self._h = None
+            self._keepalive = []
 
     __del__ = close
 
@@ -62,7 +64,10 @@ class GpuScene:
         _lib.check(self._lib.rt_scene_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
 
     def sync(self):
-        _lib.check(self._lib.rt_sync(self._h))
+        try:
+            _lib.check(self._lib.rt_sync(self._h))
+        finally:
+            self._keepalive.clear()
 
     # -- the hot path -------------------------------------------------------------------------
     def render(self, camera, width, height, n_shadow, max_depth, *, precision="fp64", jitter=None,
@@ -84,6 +89,8 @@ class GpuScene:
                         int(max_depth), prec, int(jit.mode), jit.seed & 0xFFFFFFFF, fmt, int(flags))
         st = stats if stats is not None else _lib.Stats()
         if out_ptr is not None:
+            if flags & _lib.RT_FLAG_ASYNC:
+                self._keepalive.append(st)
             _lib.check(self._lib.rt_render(self._h, C.byref(cam), C.byref(fr), C.c_void_p(out_ptr), 1, C.byref(st)))
             return None
         rows = len(rows_in_part(height, block_rows, part, n_parts))
