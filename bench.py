@@ -180,7 +180,7 @@ def main():
                     traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": "k_shade_fast" if precision == "fp32" else "k_shade_exact",
+            roofline = {"bound": "valu", "kernel": ("k_shade_small / k_shade_fast (fp32 shading)" if precision == "fp32" else "k_shade_exact"),
                         "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
                         "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
