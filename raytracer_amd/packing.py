@@ -42,15 +42,17 @@ def pack_surfaces(surfaces, n_materials=None):
     surf_data = np.zeros((n, 8), dtype=np.float64)
     surf_material = np.zeros(n, dtype=np.int32)
     for k, s in enumerate(surfaces):
-        if isinstance(s, Sphere):
+        # Duck-typed on the attribute names of the reference's classes (sphere.py:6-8,
+        # infinite_plane.py:6-9, cube.py:6-12), so the reference's own objects pack unchanged.
+        if isinstance(s, Sphere) or (hasattr(s, "radius") and hasattr(s, "position")):
             surf_type[k] = SURF_SPHERE
             surf_data[k, 0:3] = s.position
             surf_data[k, 3] = s.radius
-        elif isinstance(s, InfinitePlane):
+        elif isinstance(s, InfinitePlane) or (hasattr(s, "normal") and hasattr(s, "offset")):
             surf_type[k] = SURF_PLANE
             surf_data[k, 0:3] = s.normal
             surf_data[k, 3] = s.offset
-        elif isinstance(s, Cube):
+        elif isinstance(s, Cube) or (hasattr(s, "min_bound") and hasattr(s, "max_bound")):
             surf_type[k] = SURF_BOX
             surf_data[k, 0:3] = s.min_bound
             surf_data[k, 3:6] = s.max_bound
