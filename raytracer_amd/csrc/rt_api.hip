@@ -19,6 +19,7 @@
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
 #include "rt_shade_small.hpp"
+#include "rt_shade_ls.hpp"
 
 using namespace rt;
 
@@ -68,7 +69,7 @@ struct rt_scene {
   DevScene ds{};
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
   bool all_opaque = true;
-  bool force_general = false;   // RT_FORCE_GENERAL=1: skip the small-scene kernel (testing)
+  int shade_variant = 0;   // RT_SHADE=ls|small|general: first fp32 shade kernel tried (A/B testing)
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
@@ -164,7 +165,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
-  if (const char* e = getenv("RT_FORCE_GENERAL")) s->force_general = e[0] == '1';
+  if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 's' ? 1 : (e[0] == 'g' ? 2 : 0);
   *out = s;
   return RT_OK;
 }
@@ -335,7 +336,10 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
         else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
-        if (s->force_general || !launch_shade_small(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream))
+        bool done = false;
+        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+        if (!done && s->shade_variant <= 1) done = launch_shade_small(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+        if (!done)
           launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
       }
     }

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
   }
 }
 
+#ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)
 // Chunk size for an n x n grid: the candidate with the least padding, larger preferred.
 static inline int pick_chunk(int n_cells) {
   const int cand[] = {25, 16, 9, 4, 1};
@@ -241,5 +242,7 @@ static void launch_shade_fast(const DevScene& ds, bool opaque, const DevCamera& 
     default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
   }
 }
+
+#endif  // RT_NO_LAUNCHERS
 
 }  // namespace rt

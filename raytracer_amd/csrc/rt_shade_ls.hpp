@@ -1,0 +1,397 @@
+// rt_shade_ls.hpp — fp32 shading kernel for small scenes in "light space": the dominant kernel of
+// the headline benchmark (pool.txt class: <= MAXS spheres, MAXP planes, MAXB boxes).
+//
+// Same contract as k_shade_small / k_shade_fast (see rt_shade_fast.hpp for why the product over
+// all surface crossings equals the reference's shadow walk, ray_tracer.py:247-293, and why the
+// origin-dependent terms are formed in fp64 from the exact hit point).  What is new here:
+//
+//  * A shadow sample of light L is S = Lp + oi*right + oj*up (ray_tracer.py:224-229), so the
+//    UNNORMALISED shadow vector is ts = tl + oi*right + oj*up with tl = Lp - p.  Every dot product
+//    the intersection tests need is therefore affine in (oi, oj):
+//        oc.ts = A + oi*B + oj*C          (A = oc.tl, B = oc.right, C = oc.up; per hit/light/sphere)
+//        N.ts  = D0 + oi*D1 + oj*D2       (per hit/light/plane)
+//        ts.ts = T0 + oi*(T1 + oi) + oj*(T2 + oj)     (right, up orthonormal)
+//    and the ray p + tau*ts reaches the sample at tau = 1.  A sphere crossing solves
+//        tau*|ts|^2 = -(oc.ts) +- sqrt((oc.ts)^2 - |ts|^2*cc),   in range iff 0 < tau*|ts|^2 < |ts|^2.
+//    No per-sample normalisation (no rsq, no direction vector), 2 FMAs instead of a 3-term dot per
+//    sphere, and only (oi, oj, |ts|^2) per sample: the loop nest can be sample-outer /
+//    primitive-inner with all primitive terms in registers and no per-sample arrays.
+//  * Two samples are processed per iteration in the two halves of 64-bit register pairs
+//    (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): measured on MI355X, packed FMA issues ~1.25x
+//    the flops of v_fma_f32 (profiles/r01_valu_rates_microbench.txt).
+//  * The in-range test "0 < u < d2" is ONE unsigned integer compare on the float bit patterns
+//    (negative u and NaN from a negative discriminant both have larger bit patterns than any
+//    positive finite d2).  The lower bound is 0 instead of the reference's 2e-6 along the ray; the
+//    two differ only when the light is behind the hit's own surface, where diffuse is zero.  For an
+//    own PLANE the reference lets such rays through when |n.d| >= 0.5 (the own-surface hit at
+//    t = 1e-6/|n.d| fails its t > 1e-6 test after the 1e-6 origin shift); that is reproduced exactly
+//    by a per-wave slow path (PLANE_LO) taken only when some lane has that configuration.
+#pragma once
+#include "rt_kernels.hpp"
+#include "rt_shade_fast.hpp"
+
+namespace rt {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f pk_sqrt(v2f a) { v2f r; r.x = raw_sqrt(a.x); r.y = raw_sqrt(a.y); return r; }
+__device__ __forceinline__ v2f pk_rcp(v2f a) { v2f r; r.x = raw_rcp(a.x); r.y = raw_rcp(a.y); return r; }
+// 0 <= u < hi for hi positive finite, as ONE unsigned compare of the bit patterns: negative u
+// (sign bit set), NaN and +inf all compare above any positive finite hi.
+__device__ __forceinline__ bool in_open(float u, float hi) { return __float_as_uint(u) < __float_as_uint(hi); }
+
+constexpr int LS_MAX_CELLS = 1024;   // lights x n^2 entries of the per-block sample table (8 KiB)
+
+// Per-hit (cc, sgn, num, box slabs) and per-light (A, B, C, D*) primitive terms live in plain local
+// arrays of the kernel (fully unrolled, compile-time indices -> VGPRs); this is a view of references
+// so the sample loop can be a function.  (A struct of arrays was partly promoted to LDS by hipcc.)
+template <int MAXS, int MAXP, int MAXB, bool OPAQUE>
+struct LsPrims {
+  const float (&cc)[MAXS]; const float (&A)[MAXS]; const float (&B)[MAXS]; const float (&C)[MAXS];
+  const float (&sgn)[MAXS]; const float (&tauS)[MAXS];
+  const float (&num)[MAXP]; const float (&D0)[MAXP]; const float (&D1)[MAXP]; const float (&D2)[MAXP]; const float (&tauP)[MAXP];
+  const float (&blo)[MAXB > 0 ? MAXB : 1][3]; const float (&bhi)[MAXB > 0 ? MAXB : 1][3];
+  const float (&tauB)[MAXB > 0 ? MAXB : 1]; const bool (&binside)[MAXB > 0 ? MAXB : 1];
+};
+
+// Transmission sum of one light for one hit: sum over the n x n cells of the product of blocker
+// transparencies (opaque scenes: count of unblocked cells).  Two cells per iteration.
+//
+// Opaque scenes keep the "blocked" state out of the scalar unit: every candidate crossing is
+// expressed as u = tau*|ts|^2 and folded into an UNSIGNED MINIMUM of float bit patterns
+// (v_min_u32 / v_min3_u32); the cell is blocked iff min_bits < bits(|ts|^2) (see in_open).  A
+// compare per test would put ~3 SALU mask operations per VALU compare into the wave's instruction
+// stream (measured: 170 SALU vs 134 VALU instructions per pair, no faster than k_shade_small).
+// NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6, 8; unused slots hold A = B = C = 0,
+// cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
+template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool PLANE_LO>
+__device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, int nP, int nB,
+                                              const float2* __restrict__ cells, int n_cells, uint32_t key, float cell16,
+                                              f3 tl, f3 right, f3 up, float T0, float T1, float T2) {
+  float total = 0.0f;
+  const int n_pairs = (n_cells + 1) >> 1;
+#pragma unroll 1
+  for (int q = 0; q < n_pairs; ++q) {
+    const int c0 = 2 * q, c1 = 2 * q + 1;
+    const bool valid1 = c1 < n_cells;                                       // wave-uniform
+    const float2 b0 = cells[c0], b1 = cells[valid1 ? c1 : c0];              // LDS broadcast reads
+    const uint32_t h0 = jit_cell_bits(key, (uint32_t)c0), h1 = jit_cell_bits(key, (uint32_t)c1);
+    v2f oi, oj;                                                             // ray_tracer.py:224-225
+    oi.x = fmaf((float)(h0 >> 16), cell16, b0.x); oi.y = fmaf((float)(h1 >> 16), cell16, b1.x);
+    oj.x = fmaf((float)(h0 & 0xFFFFu), cell16, b0.y); oj.y = fmaf((float)(h1 & 0xFFFFu), cell16, b1.y);
+    const v2f d2 = pk_fma(oi, splat(T1) + oi, pk_fma(oj, splat(T2) + oj, splat(T0)));   // |ts|^2
+    uint32_t m0 = 0xFFFFFFFFu, m1 = valid1 ? 0xFFFFFFFFu : 0u;             // min of candidate bit patterns
+    v2f tr = splat(1.0f);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {                                          // spheres: sphere.py:49-71
+      const v2f bt = pk_fma(oj, splat(pr.C[k]), pk_fma(oi, splat(pr.B[k]), splat(pr.A[k])));   // oc.ts
+      const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(pr.cc[k]))));                         // NaN on a miss
+      if (OPAQUE) {
+        const v2f u = pk_fma(splat(pr.sgn[k]), sq, -bt);                    // far root iff origin inside
+        m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y));
+      } else {
+        const v2f u1 = -bt - sq, u2 = sq - bt;
+        const float ta = pr.tauS[k];
+        tr.x *= in_open(u1.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u1.y, d2.y) ? ta : 1.0f;
+        tr.x *= in_open(u2.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u2.y, d2.y) ? ta : 1.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
+      if (k < nP) {
+        const v2f den = pk_fma(oj, splat(pr.D2[k]), pk_fma(oi, splat(pr.D1[k]), splat(pr.D0[k])));   // N.ts
+        const v2f tau = splat(pr.num[k]) * pk_rcp(den);                    // den == 0 -> inf/NaN -> miss
+        v2f u = tau * d2;                                                   // same scale as the sphere roots
+        if (PLANE_LO) {   // exact lower bound of the reference: tau*|ts| > 2e-6 (own plane, light behind it)
+          const v2f t2 = tau * u;
+          u.x = t2.x > T_LO * T_LO ? u.x : -1.0f; u.y = t2.y > T_LO * T_LO ? u.y : -1.0f;
+        }
+        if (OPAQUE) { m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y)); }
+        else { const float ta = pr.tauP[k]; tr.x *= in_open(u.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u.y, d2.y) ? ta : 1.0f; }
+      }
+    }
+    if (MAXB > 0) {                                                         // boxes: cube.py:76-107 (slab roots)
+      if (nB > 0) {
+        const v2f ix = pk_rcp(pk_fma(oj, splat(up.x), pk_fma(oi, splat(right.x), splat(tl.x))));
+        const v2f iy = pk_rcp(pk_fma(oj, splat(up.y), pk_fma(oi, splat(right.y), splat(tl.y))));
+        const v2f iz = pk_rcp(pk_fma(oj, splat(up.z), pk_fma(oi, splat(right.z), splat(tl.z))));
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) {
+          if (k < nB) {
+            const v2f ax = splat(pr.blo[k][0]) * ix, bx = splat(pr.bhi[k][0]) * ix;
+            const v2f ay = splat(pr.blo[k][1]) * iy, by = splat(pr.bhi[k][1]) * iy;
+            const v2f az = splat(pr.blo[k][2]) * iz, bz = splat(pr.bhi[k][2]) * iz;
+            v2f tn, tf;                                                     // slab parameters are tau already
+            tn.x = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+            tn.y = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+            tf.x = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
+            tf.y = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+            if (OPAQUE) {
+              // entry root, or the exit root when the origin is inside; -1 (never in range) if the slabs miss
+              const float t0 = tn.x <= tf.x ? (pr.binside[k] ? tf.x : tn.x) : -1.0f;
+              const float t1 = tn.y <= tf.y ? (pr.binside[k] ? tf.y : tn.y) : -1.0f;
+              m0 = min(m0, __float_as_uint(t0 * d2.x)); m1 = min(m1, __float_as_uint(t1 * d2.y));
+            } else {
+              const float ta = pr.tauB[k];
+              const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
+              tr.x *= (ok0 & in_open(tn.x, 1.0f)) ? ta : 1.0f; tr.y *= (ok1 & in_open(tn.y, 1.0f)) ? ta : 1.0f;
+              tr.x *= (ok0 & in_open(tf.x, 1.0f)) ? ta : 1.0f; tr.y *= (ok1 & in_open(tf.y, 1.0f)) ? ta : 1.0f;
+            }
+          }
+        }
+      }
+    }
+    if (OPAQUE) total += (m0 < __float_as_uint(d2.x) ? 0.0f : 1.0f) + (m1 < __float_as_uint(d2.y) ? 0.0f : 1.0f);
+    else total += tr.x + (valid1 ? tr.y : 0.0f);
+  }
+  return total;
+}
+
+template <int MAXS, int MAXP, int MAXB, bool OPAQUE>
+__global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                    RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
+                                                    float* __restrict__ fb) {
+  constexpr int MAXN = MAXS + MAXP + MAXB;
+  __shared__ Prim s_prims[MAXN];
+  __shared__ float2 s_cells[LS_MAX_CELLS];
+  __shared__ uint32_t s_wcnt[BLOCK / 64][2];
+  __shared__ uint32_t s_base;
+  const int n_sh = fp.n_shadow;
+  const int n_side = n_sh > 1 ? n_sh : 1;
+  const int n_cells = n_side * n_side;
+  {
+    const int words = sc.n * (int)(sizeof(Prim) / 16);
+    const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
+    uint4* dst = reinterpret_cast<uint4*>(s_prims);
+    for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    // per-light table of cell base offsets: -radius/2 + cell*(i or j)   (ray_tracer.py:215, 224-225)
+    for (int e = threadIdx.x; e < sc.nL * n_cells; e += BLOCK) {
+      const int li = e / n_cells, c = e - li * n_cells;
+      const float radius = (float)sc.lights[LIGHT_STRIDE * li + 8];
+      const float cell = radius / (float)n_side, half = -0.5f * radius;
+      const int i = c / n_side, j = c - i * n_side;
+      s_cells[e] = n_sh > 1 ? make_float2(fmaf(cell, (float)i, half), fmaf(cell, (float)j, half)) : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+  }
+  const Prim* P = s_prims;
+  const int nS = sc.nS, nP = sc.nP, nB = sc.nB;
+  uint32_t count = C->n_hits[level];
+  if (count > fp.queue_cap) count = fp.queue_cap;
+  const uint32_t n_iters = (count + BLOCK - 1) / BLOCK;
+  const float inv_cells = 1.0f / (float)n_cells;
+  const bool spawn_level = level < fp.max_depth;
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+
+  for (uint32_t iter = blockIdx.x; iter < n_iters; iter += gridDim.x) {
+    const uint32_t h = iter * BLOCK + threadIdx.x;
+    const bool active = h < count;
+    // ---------------------------------------------------------------- phase 1: per-hit setup ---
+    float a_cc[MAXS], a_A[MAXS], a_B[MAXS], a_C[MAXS], a_sgn[MAXS], a_tauS[MAXS];
+    float a_num[MAXP], a_D0[MAXP], a_D1[MAXP], a_D2[MAXP], a_tauP[MAXP];
+    float a_blo[MAXB > 0 ? MAXB : 1][3], a_bhi[MAXB > 0 ? MAXB : 1][3], a_tauB[MAXB > 0 ? MAXB : 1];
+    bool a_binside[MAXB > 0 ? MAXB : 1];
+    const LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_cc, a_A, a_B, a_C, a_sgn, a_tauS, a_num, a_D0, a_D1, a_D2, a_tauP,
+                                               a_blo, a_bhi, a_tauB, a_binside};
+    d3 p = mk3(0, 0, 0);
+    f3 nf = mkf(0, 0, 1), v = mkf(0, 0, 1), wgt = mkf(0, 0, 0);
+    int mat_idx = 0, own = -1;
+    bool own_is_plane = false;
+    uint32_t lp = 0, gpix = 0;
+    if (active) {
+      const HitRec hr = hits[h];
+      const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
+      const Prim& op = P[hr.prim];
+      const d3 n = prim_normal(op, r.o, r.d, hr.t);
+      const d3 hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
+      p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);
+      v = normalize_clamped(mkf((float)(r.o.x - hp.x), (float)(r.o.y - hp.y), (float)(r.o.z - hp.z)));
+      nf = tof(n);
+      mat_idx = op.mat; own = hr.prim; own_is_plane = op.type == 1;
+      lp = r.lp; gpix = global_pixel(fp.rs, lp);
+      wgt = tof(r.w);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+      a_cc[k] = 1.0f; a_sgn[k] = -1.0f;
+      if (k < nS) {
+        const Prim& s_ = P[k];
+        const double ox = p.x - s_.a[0], oy = p.y - s_.a[1], oz = p.z - s_.a[2];
+        a_cc[k] = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
+        a_sgn[k] = a_cc[k] < 0.0f ? 1.0f : -1.0f;
+        a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      a_num[k] = 0.0f;
+      if (k < nP) {
+        const Prim& s_ = P[nS + k];
+        a_num[k] = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
+        a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) {
+      if (k < nB) {
+        const Prim& s_ = P[nS + nP + k];
+        a_blo[k][0] = (float)(s_.a[0] - p.x); a_blo[k][1] = (float)(s_.a[1] - p.y); a_blo[k][2] = (float)(s_.a[2] - p.z);
+        a_bhi[k][0] = (float)(s_.a[3] - p.x); a_bhi[k][1] = (float)(s_.a[4] - p.y); a_bhi[k][2] = (float)(s_.a[5] - p.z);
+        a_binside[k] = (a_blo[k][0] < 0.0f) & (a_blo[k][1] < 0.0f) & (a_blo[k][2] < 0.0f) &
+                        (a_bhi[k][0] > 0.0f) & (a_bhi[k][1] > 0.0f) & (a_bhi[k][2] > 0.0f);
+        a_tauB[k] = 0.0f; if (!OPAQUE) a_tauB[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+      }
+    }
+    const double* mat = sc.mats + MAT_STRIDE * mat_idx;
+
+    // ------------------------------------------------------------- phase 2: lights & shadows ---
+    float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
+    for (int li = 0; li < sc.nL; ++li) {
+      const double* lg = sc.lights + LIGHT_STRIDE * li;
+      const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
+      const float T0 = dotf(tl, tl);
+      const float rl = raw_rsq(T0);
+      const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
+      const f3 ref = (fabsf(ld.x) >= 0.9f) ? mkf(0, 1, 0) : mkf(1, 0, 0);
+      const f3 right = normalize_clamped(crossf(ld, ref));
+      const f3 up = normalize_clamped(crossf(right, ld));
+      const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
+      const float radius = (float)lg[8];
+      const float cell16 = n_sh > 1 ? (radius / (float)n_side) * (1.0f / 65536.0f) : 0.0f;
+      const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k) {
+        a_A[k] = a_B[k] = a_C[k] = 0.0f;
+        if (k < nS) {
+          const Prim& s_ = P[k];
+          const f3 oc = mkf((float)(p.x - s_.a[0]), (float)(p.y - s_.a[1]), (float)(p.z - s_.a[2]));
+          a_A[k] = dotf(oc, tl); a_B[k] = dotf(oc, right); a_C[k] = dotf(oc, up);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        a_D0[k] = a_D1[k] = a_D2[k] = 0.0f;
+        if (k < nP) {
+          const Prim& s_ = P[nS + k];
+          const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+          a_D0[k] = dotf(N, tl); a_D1[k] = dotf(N, right); a_D2[k] = dotf(N, up);
+        }
+      }
+      // Slow path only if some lane's own surface is a plane with the light (partly) behind it.
+      const float nt = dotf(nf, tl);
+      const bool need_lo = own_is_plane & (nt < 0.71f * radius);
+      const float2* cells = s_cells + li * n_cells;
+      float total;
+      if (__any(need_lo))
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, nP, nB, cells, n_cells, key, cell16, tl, right, up,
+                                                                   T0, T1, T2);
+      else
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, nP, nB, cells, n_cells, key, cell16, tl, right, up,
+                                                                    T0, T1, T2);
+      const float T = total * inv_cells;
+      const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                         // ray_tracer.py:543
+      // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
+      const float ndl = fmaxf(nt * rl, 0.0f);
+      const float s1 = I * ndl;
+      dif0 = fmaf((float)mat[0] * (float)lg[3], s1, dif0);
+      dif1 = fmaf((float)mat[1] * (float)lg[4], s1, dif1);
+      dif2 = fmaf((float)mat[2] * (float)lg[5], s1, dif2);
+      const float dn = -nt * rl;                                                          // (-l).n
+      const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -ld.x), fmaf(-2.0f * dn, nf.y, -ld.y), fmaf(-2.0f * dn, nf.z, -ld.z));
+      const float rdv = fmaxf(dotf(rf, v), 0.0f);
+      const float shin = (float)mat[9];
+      const float pw = (shin == 0.0f) ? 1.0f : (rdv > 0.0f ? powf(rdv, shin) : 0.0f);     // np.power(0, 0) == 1
+      const float s2 = I * pw * (float)lg[6];
+      spc0 = fmaf((float)mat[3] * (float)lg[3], s2, spc0);
+      spc1 = fmaf((float)mat[4] * (float)lg[4], s2, spc1);
+      spc2 = fmaf((float)mat[5] * (float)lg[5], s2, spc2);
+    }
+    (void)own;
+
+    // ------------------------------------------------- phase 3: accumulate, spawn children -----
+    if (active) {
+      const float one_m = 1.0f - (float)mat[10];
+      const float c0 = wgt.x * ((dif0 + spc0) * one_m), c1 = wgt.y * ((dif1 + spc1) * one_m), c2 = wgt.z * ((dif2 + spc2) * one_m);
+      float* dst = fb + 3 * (size_t)lp;
+      if (level == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
+      else { atomicAdd(dst + 0, c0); atomicAdd(dst + 1, c1); atomicAdd(dst + 2, c2); }
+    }
+    if (spawn_level) {                                                     // ray_tracer.py:565-595
+      const bool needT = active && (mat[10] > EPS);
+      const bool needR = active && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS);
+      const unsigned long long mT = __ballot(needT), mR = __ballot(needR);
+      if (lane == 0) { s_wcnt[wave][0] = (uint32_t)__popcll(mT); s_wcnt[wave][1] = (uint32_t)__popcll(mR); }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) tot += s_wcnt[w][0] + s_wcnt[w][1];
+        s_base = tot ? atomicAdd(&C->n_rays[level + 1], tot) : 0u;
+      }
+      __syncthreads();
+      uint32_t base = s_base;
+      for (uint32_t w = 0; w < wave; ++w) base += s_wcnt[w][0] + s_wcnt[w][1];
+      const uint32_t preT = __builtin_amdgcn_mbcnt_hi((uint32_t)(mT >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mT, 0u));
+      const uint32_t preR = __builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
+      const uint32_t sT = base + preT, sR = base + (uint32_t)__popcll(mT) + preR;
+      if (needT || needR) {
+        // recompute the fp64 hit geometry (cheaper than keeping ~30 VGPRs live through phase 2)
+        const HitRec hr = hits[h];
+        const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
+        const d3 n = prim_normal(P[hr.prim], r.o, r.d, hr.t);
+        const d3 hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
+        if (needT) {
+          if (sT < fp.queue_cap) {
+            nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
+            nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
+            nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
+            nq.pix[sT] = r.lp;
+          } else C->overflow = 1u;
+        }
+        if (needR) {
+          if (sR < fp.queue_cap) {
+            const double dn = dot3(r.d, n);                                // reflect_batch, :34-36
+            nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
+            nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
+            nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
+            nq.pix[sR] = r.lp;
+          } else C->overflow = 1u;
+        }
+      }
+      __syncthreads();   // s_wcnt / s_base are reused by the next iteration
+    }
+  }
+}
+
+#ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)
+// Scenes served: up to 8 spheres + 2 planes without boxes, or up to 4 spheres + 2 planes + 4 boxes,
+// any shadow grid with lights * n^2 <= LS_MAX_CELLS.  Returns false -> caller uses another kernel.
+static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
+                            RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                            hipStream_t st) {
+  const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
+  if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2) return false;
+#define RT_LS(S, Pn, B)                                                                                             \
+  do {                                                                                                              \
+    if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
+                                   cur, nxt, hits, C, fb);                                                           \
+    else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur,  \
+                            nxt, hits, C, fb);                                                                       \
+    return true;                                                                                                    \
+  } while (0)
+  if (ds.nB == 0) {
+    if (ds.nS <= 2) RT_LS(2, 2, 0);
+    if (ds.nS <= 4) RT_LS(4, 2, 0);
+    if (ds.nS <= 6) RT_LS(6, 2, 0);
+    if (ds.nS <= 8) RT_LS(8, 2, 0);
+  } else if (ds.nB <= 4) {
+    if (ds.nS <= 2) RT_LS(2, 2, 4);
+    if (ds.nS <= 4) RT_LS(4, 2, 4);
+  }
+#undef RT_LS
+  return false;
+}
+
+#endif  // RT_NO_LAUNCHERS
+
+}  // namespace rt

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_small(DevScene sc, DevCamera ca
   }
 }
 
+#ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)
 // Can this (scene, frame) be served by a k_shade_small instantiation?  Returns false -> use
 // k_shade_fast.  Instantiated shapes: (8 spheres, 2 planes, 0 boxes) and (4, 2, 4); shadow grids
 // n <= 1 and n in {2, 3, 4, 5, 8}.
@@ -325,5 +326,7 @@ static bool launch_shade_small(const DevScene& ds, bool opaque, const DevCamera&
     return launch_small_shape<4, 2, 4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st);
   return false;
 }
+
+#endif  // RT_NO_LAUNCHERS
 
 }  // namespace rt
