@@ -66,7 +66,7 @@ struct LsPrims {
 // NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6, 8; unused slots hold A = B = C = 0,
 // cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
 template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool PLANE_LO>
-__device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, int nP, int nB,
+__device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
                                               const float2* __restrict__ cells, int n_cells, uint32_t key, float cell16,
                                               f3 tl, f3 right, f3 up, float T0, float T1, float T2) {
   float total = 0.0f;
@@ -85,6 +85,7 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
     v2f tr = splat(1.0f);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {                                          // spheres: sphere.py:49-71
+      if (!(act & (1u << k))) continue;                                     // culled for this (wave, light)
       const v2f bt = pk_fma(oj, splat(pr.C[k]), pk_fma(oi, splat(pr.B[k]), splat(pr.A[k])));   // oc.ts
       const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(pr.cc[k]))));                         // NaN on a miss
       if (OPAQUE) {
@@ -99,7 +100,7 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
     }
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
-      if (k < nP) {
+      if (act & (0x10000u << k)) {
         const v2f den = pk_fma(oj, splat(pr.D2[k]), pk_fma(oi, splat(pr.D1[k]), splat(pr.D0[k])));   // N.ts
         const v2f tau = splat(pr.num[k]) * pk_rcp(den);                    // den == 0 -> inf/NaN -> miss
         v2f u = tau * d2;                                                   // same scale as the sphere roots
@@ -281,13 +282,46 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       // Slow path only if some lane's own surface is a plane with the light (partly) behind it.
       const float nt = dotf(nf, tl);
       const bool need_lo = own_is_plane & (nt < 0.71f * radius);
+      // Conservative per-(wave, light) culling: a primitive is tested only if it can cross the
+      // shadow segment of SOME sample of this light for SOME lane of the wave (results unchanged).
+      // Every sample lies within RL of the light centre, so the segment p -> sample stays within RL
+      // of the segment p -> Lp.
+      uint32_t act = 0;
+      {
+        // Sphere k can cross the segment p -> S of some sample S only if, for some tau in [0,1],
+        // |oc + tau*tl| <= r + tau*RL (the segments to all samples fan out inside a cone around
+        // p -> Lp):  g(tau) = tau^2 (T0 - RL^2) + 2 tau (A - r RL) + cc <= 0, minimised on [0,1].
+        const float RL = 0.7072f * radius * 1.001f;
+        const float qa = T0 - RL * RL, rqa = raw_rcp(qa);
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+          if (k < nS) {
+            const float r = (float)P[k].a[3];
+            const float qb = a_A[k] - r * RL;
+            const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
+            const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), a_cc[k]);
+            const bool can = (qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(a_cc[k]) + r * r));
+            if (__any(active & can)) act |= 1u << k;
+          }
+        }
+        const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+          if (k < nP) {
+            const float spread = hw * (fabsf(a_D1[k]) + fabsf(a_D2[k])) + 1e-6f * fabsf(a_D0[k]);
+            // tau = num / den in (0, 1) needs num and den of the same sign
+            const bool can = a_num[k] < 0.0f ? (a_D0[k] - spread <= 0.0f) : (a_num[k] > 0.0f ? (a_D0[k] + spread >= 0.0f) : true);
+            if (__any(active & can)) act |= 0x10000u << k;
+          }
+        }
+      }
       const float2* cells = s_cells + li * n_cells;
       float total;
       if (__any(need_lo))
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, nP, nB, cells, n_cells, key, cell16, tl, right, up,
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell16, tl, right, up,
                                                                    T0, T1, T2);
       else
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, nP, nB, cells, n_cells, key, cell16, tl, right, up,
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell16, tl, right, up,
                                                                     T0, T1, T2);
       const float T = total * inv_cells;
       const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                         // ray_tracer.py:543
