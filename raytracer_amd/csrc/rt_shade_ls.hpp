@@ -42,6 +42,8 @@ __device__ __forceinline__ v2f pk_rcp(v2f a) { v2f r; r.x = raw_rcp(a.x); r.y = 
 __device__ __forceinline__ bool in_open(float u, float hi) { return __float_as_uint(u) < __float_as_uint(hi); }
 
 constexpr int LS_MAX_CELLS = 1024;   // lights x n^2 entries of the per-block sample table (8 KiB)
+constexpr int LS_MAX_LIGHTS = 16;    // lights / materials staged in LDS (uniform global loads inside the
+constexpr int LS_MAX_MATS = 32;      // light loop were emitted as vector loads + full-latency waits)
 
 // Per-hit (cc, sgn, num, box slabs) and per-light (A, B, C, D*) primitive terms live in plain local
 // arrays of the kernel (fully unrolled, compile-time indices -> VGPRs); this is a view of references
@@ -71,11 +73,18 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
                                               f3 tl, f3 right, f3 up, float T0, float T1, float T2) {
   float total = 0.0f;
   const int n_pairs = (n_cells + 1) >> 1;
+  // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
+  // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
+  float2 nb0 = cells[0], nb1 = cells[n_cells > 1 ? 1 : 0];
 #pragma unroll 1
   for (int q = 0; q < n_pairs; ++q) {
     const int c0 = 2 * q, c1 = 2 * q + 1;
     const bool valid1 = c1 < n_cells;                                       // wave-uniform
-    const float2 b0 = cells[c0], b1 = cells[valid1 ? c1 : c0];              // LDS broadcast reads
+    const float2 b0 = nb0, b1 = nb1;
+    {
+      const int p0 = c0 + 2 < n_cells ? c0 + 2 : 0, p1 = c1 + 2 < n_cells ? c1 + 2 : 0;
+      nb0 = cells[p0]; nb1 = cells[p1];
+    }
     const uint32_t h0 = jit_cell_bits(key, (uint32_t)c0), h1 = jit_cell_bits(key, (uint32_t)c1);
     v2f oi, oj;                                                             // ray_tracer.py:224-225
     oi.x = fmaf((float)(h0 >> 16), cell16, b0.x); oi.y = fmaf((float)(h1 >> 16), cell16, b1.x);
@@ -156,6 +165,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   constexpr int MAXN = MAXS + MAXP + MAXB;
   __shared__ Prim s_prims[MAXN];
   __shared__ float2 s_cells[LS_MAX_CELLS];
+  __shared__ double s_lightd[LS_MAX_LIGHTS][LIGHT_STRIDE];   // as uploaded (position needs fp64)
+  __shared__ double s_matd[LS_MAX_MATS][MAT_STRIDE];
   __shared__ uint32_t s_wcnt[BLOCK / 64][2];
   __shared__ uint32_t s_base;
   const int n_sh = fp.n_shadow;
@@ -166,6 +177,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
     uint4* dst = reinterpret_cast<uint4*>(s_prims);
     for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < sc.nL * LIGHT_STRIDE; i += BLOCK) (&s_lightd[0][0])[i] = sc.lights[i];
+    for (int i = threadIdx.x; i < sc.nM * MAT_STRIDE; i += BLOCK) (&s_matd[0][0])[i] = sc.mats[i];
     // per-light table of cell base offsets: -radius/2 + cell*(i or j)   (ray_tracer.py:215, 224-225)
     for (int e = threadIdx.x; e < sc.nL * n_cells; e += BLOCK) {
       const int li = e / n_cells, c = e - li * n_cells;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         const double ox = p.x - s_.a[0], oy = p.y - s_.a[1], oz = p.z - s_.a[2];
         a_cc[k] = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
         a_sgn[k] = a_cc[k] < 0.0f ? 1.0f : -1.0f;
-        a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+        a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
 #pragma unroll
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       if (k < nP) {
         const Prim& s_ = P[nS + k];
         a_num[k] = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
-        a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+        a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)s_matd[s_.mat][10];
       }
     }
 #pragma unroll
@@ -241,15 +254,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         a_bhi[k][0] = (float)(s_.a[3] - p.x); a_bhi[k][1] = (float)(s_.a[4] - p.y); a_bhi[k][2] = (float)(s_.a[5] - p.z);
         a_binside[k] = (a_blo[k][0] < 0.0f) & (a_blo[k][1] < 0.0f) & (a_blo[k][2] < 0.0f) &
                         (a_bhi[k][0] > 0.0f) & (a_bhi[k][1] > 0.0f) & (a_bhi[k][2] > 0.0f);
-        a_tauB[k] = 0.0f; if (!OPAQUE) a_tauB[k] = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+        a_tauB[k] = 0.0f; if (!OPAQUE) a_tauB[k] = (float)s_matd[s_.mat][10];
       }
     }
-    const double* mat = sc.mats + MAT_STRIDE * mat_idx;
+    const double* mat = s_matd[mat_idx];
+    // material terms of this hit in registers (fp32) for the light loop
+    const float kd0 = (float)mat[0], kd1 = (float)mat[1], kd2 = (float)mat[2];
+    const float ks0 = (float)mat[3], ks1 = (float)mat[4], ks2 = (float)mat[5];
+    const float shin = (float)mat[9];
 
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
     for (int li = 0; li < sc.nL; ++li) {
-      const double* lg = sc.lights + LIGHT_STRIDE * li;
+      const double* lg = s_lightd[li];
       const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
@@ -328,18 +345,17 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
       const float ndl = fmaxf(nt * rl, 0.0f);
       const float s1 = I * ndl;
-      dif0 = fmaf((float)mat[0] * (float)lg[3], s1, dif0);
-      dif1 = fmaf((float)mat[1] * (float)lg[4], s1, dif1);
-      dif2 = fmaf((float)mat[2] * (float)lg[5], s1, dif2);
+      dif0 = fmaf(kd0 * (float)lg[3], s1, dif0);
+      dif1 = fmaf(kd1 * (float)lg[4], s1, dif1);
+      dif2 = fmaf(kd2 * (float)lg[5], s1, dif2);
       const float dn = -nt * rl;                                                          // (-l).n
       const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -ld.x), fmaf(-2.0f * dn, nf.y, -ld.y), fmaf(-2.0f * dn, nf.z, -ld.z));
       const float rdv = fmaxf(dotf(rf, v), 0.0f);
-      const float shin = (float)mat[9];
       const float pw = (shin == 0.0f) ? 1.0f : (rdv > 0.0f ? powf(rdv, shin) : 0.0f);     // np.power(0, 0) == 1
       const float s2 = I * pw * (float)lg[6];
-      spc0 = fmaf((float)mat[3] * (float)lg[3], s2, spc0);
-      spc1 = fmaf((float)mat[4] * (float)lg[4], s2, spc1);
-      spc2 = fmaf((float)mat[5] * (float)lg[5], s2, spc2);
+      spc0 = fmaf(ks0 * (float)lg[3], s2, spc0);
+      spc1 = fmaf(ks1 * (float)lg[4], s2, spc1);
+      spc2 = fmaf(ks2 * (float)lg[5], s2, spc2);
     }
     (void)own;
 
@@ -404,7 +420,7 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
                             RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
                             hipStream_t st) {
   const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
-  if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2) return false;
+  if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
