@@ -104,10 +104,12 @@ static inline uint32_t jit_light_key(uint32_t seed, uint32_t pixel, uint32_t dep
   h = lowbias32(h + depth);
   return lowbias32(h + light);
 }
+/* per-pixel rotated lattice: u = f32(k + (cell+1)*PHI) * 2^-32 (uint32 wrap, RNE conversion) */
 static inline void jit_cell(uint32_t key, uint32_t cell, double* ui, double* uj) {
-  uint32_t x = lowbias32(key + (cell + 1u) * 0x9E3779B9u);
-  *ui = (double)(x >> 16) * (1.0 / 65536.0);
-  *uj = (double)(x & 0xFFFFu) * (1.0 / 65536.0);
+  uint32_t kb = lowbias32(key ^ 0x68E31DA4u);
+  uint32_t xa = key + (cell + 1u) * 0x9E3779B9u, xb = kb + (cell + 1u) * 0x7F4A7C15u;
+  *ui = (double)(float)xa * (1.0 / 4294967296.0);
+  *uj = (double)(float)xb * (1.0 / 4294967296.0);
 }
 void orc_jitter_cell(uint32_t seed, const uint32_t* pixels, long long n, int depth, int light, int cell,
                      double* ui, double* uj) {

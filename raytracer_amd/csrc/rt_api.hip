@@ -18,7 +18,6 @@
 #include "../../include/rt_hip.h"
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
-#include "rt_shade_small.hpp"
 #include "rt_shade_ls.hpp"
 
 using namespace rt;
@@ -69,7 +68,7 @@ struct rt_scene {
   DevScene ds{};
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
   bool all_opaque = true;
-  int shade_variant = 0;   // RT_SHADE=ls|small|general: first fp32 shade kernel tried (A/B testing)
+  int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
@@ -165,7 +164,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
-  if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 's' ? 1 : (e[0] == 'g' ? 2 : 0);
+  if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
   *out = s;
   return RT_OK;
 }
@@ -338,7 +337,6 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
         if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
-        if (!done && s->shade_variant <= 1) done = launch_shade_small(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
         if (!done)
           launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
       }

@@ -55,18 +55,26 @@ __device__ __forceinline__ d3 cross3(d3 a, d3 b) {  // np.cross
 __device__ __forceinline__ double comp(d3 v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); }
 
 // ----------------------------------------------------------------- pixel-keyed jitter (mode B) --
-// Same mixer as raytracer_amd/jitter.py and oracle/rt_oracle.c.
+// Same definition as raytracer_amd/jitter.py and oracle/rt_oracle.c.  A strong integer hash gives
+// two 32-bit words per (seed, pixel, depth, light); the uniforms of cell c are the per-pixel rotated
+// lattice  u_i = f32(ka + (c+1)*PHI_A) * 2^-32,  u_j = f32(kb + (c+1)*PHI_B) * 2^-32  (uint32 wrap,
+// f32() = round-to-nearest conversion, so u is an fp32 value in [0,1] on every platform): two
+// integer adds and two conversions per cell in the inner loop instead of a full hash.
 __host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
 }
-__host__ __device__ __forceinline__ uint32_t jit_light_key(uint32_t seed, uint32_t pixel, uint32_t depth, uint32_t light) {
+constexpr uint32_t JIT_PHI_A = 0x9E3779B9u, JIT_PHI_B = 0x7F4A7C15u, JIT_KB_XOR = 0x68E31DA4u;
+constexpr float JIT_SCALE = 2.3283064365386963e-10f;   // 2^-32
+struct JitKey { uint32_t a, b; };
+__host__ __device__ __forceinline__ JitKey jit_light_key(uint32_t seed, uint32_t pixel, uint32_t depth, uint32_t light) {
   uint32_t h = lowbias32(pixel ^ seed);
   h = lowbias32(h + depth);
-  return lowbias32(h + light);
+  h = lowbias32(h + light);
+  JitKey k; k.a = h; k.b = lowbias32(h ^ JIT_KB_XOR);
+  return k;
 }
-__host__ __device__ __forceinline__ uint32_t jit_cell_bits(uint32_t key, uint32_t cell) {
-  return lowbias32(key + (cell + 1u) * 0x9E3779B9u);   // u_i = bits>>16, u_j = bits&0xFFFF, scaled by 2^-16
-}
+__device__ __forceinline__ float jit_ui(JitKey k, uint32_t cell) { return (float)(k.a + (cell + 1u) * JIT_PHI_A) * JIT_SCALE; }
+__device__ __forceinline__ float jit_uj(JitKey k, uint32_t cell) { return (float)(k.b + (cell + 1u) * JIT_PHI_B) * JIT_SCALE; }
 
 // ------------------------------------------------------------------------ primitives, t only ---
 // Sphere.intersect_batch, surfaces/sphere.py:49-71.

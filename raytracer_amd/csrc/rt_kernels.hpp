@@ -259,13 +259,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
           up = mk3(up.x / un, up.y / un, up.z / un);
           const double radius = lg[8];
           const double cell = radius / n_sh;                                           // :215
-          const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+          const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
           double total = 0.0;
           for (int i = 0; i < n_sh; ++i)
             for (int j = 0; j < n_sh; ++j) {                                           // :219-241
-              uint32_t bits = jit_cell_bits(key, (uint32_t)(i * n_sh + j));
-              double ui = (double)(bits >> 16) * (1.0 / 65536.0);
-              double uj = (double)(bits & 0xFFFFu) * (1.0 / 65536.0);
+              double ui = (double)jit_ui(key, (uint32_t)(i * n_sh + j));
+              double uj = (double)jit_uj(key, (uint32_t)(i * n_sh + j));
               double oi = -radius / 2 + cell * (i + ui);
               double oj = -radius / 2 + cell * (j + uj);
               d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,

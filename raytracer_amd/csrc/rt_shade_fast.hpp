@@ -88,8 +88,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
         const float radius = (float)lg[8];
         const float cell = radius / (float)(n_sh > 1 ? n_sh : 1);
         const float half = -0.5f * radius;
-        const float cell16 = cell * (1.0f / 65536.0f);
-        const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+        const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
         float total = 0.0f;
         for (int c = 0; c < n_chunks; ++c) {
           float dx[CH], dy[CH], dz[CH], md[CH], tr[CH];
@@ -100,9 +99,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             f3 ts = tl;
             if (n_sh > 1) {                                   // ray_tracer.py:219-235
               const int i = cellidx / n_sh, j = cellidx - i * n_sh;
-              const uint32_t bits = jit_cell_bits(key, (uint32_t)cellidx);
-              const float oi = fmaf((float)(bits >> 16), cell16, fmaf(cell, (float)i, half));
-              const float oj = fmaf((float)(bits & 0xFFFFu), cell16, fmaf(cell, (float)j, half));
+              const float oi = fmaf(jit_ui(key, (uint32_t)cellidx), cell, fmaf(cell, (float)i, half));
+              const float oj = fmaf(jit_uj(key, (uint32_t)cellidx), cell, fmaf(cell, (float)j, half));
               ts = mkf(fmaf(oj, up.x, fmaf(oi, right.x, tl.x)), fmaf(oj, up.y, fmaf(oi, right.y, tl.y)),
                        fmaf(oj, up.z, fmaf(oi, right.z, tl.z)));
             }

@@ -69,13 +69,14 @@ struct LsPrims {
 // cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
 template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool PLANE_LO>
 __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
-                                              const float2* __restrict__ cells, int n_cells, uint32_t key, float cell16,
+                                              const float2* __restrict__ cells, int n_cells, JitKey key, float cell32,
                                               f3 tl, f3 right, f3 up, float T0, float T1, float T2) {
   float total = 0.0f;
   const int n_pairs = (n_cells + 1) >> 1;
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
   float2 nb0 = cells[0], nb1 = cells[n_cells > 1 ? 1 : 0];
+  uint32_t xa = key.a + JIT_PHI_A, xb = key.b + JIT_PHI_B;                  // cell 0 (see jit_ui / jit_uj)
 #pragma unroll 1
   for (int q = 0; q < n_pairs; ++q) {
     const int c0 = 2 * q, c1 = 2 * q + 1;
@@ -85,10 +86,10 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
       const int p0 = c0 + 2 < n_cells ? c0 + 2 : 0, p1 = c1 + 2 < n_cells ? c1 + 2 : 0;
       nb0 = cells[p0]; nb1 = cells[p1];
     }
-    const uint32_t h0 = jit_cell_bits(key, (uint32_t)c0), h1 = jit_cell_bits(key, (uint32_t)c1);
     v2f oi, oj;                                                             // ray_tracer.py:224-225
-    oi.x = fmaf((float)(h0 >> 16), cell16, b0.x); oi.y = fmaf((float)(h1 >> 16), cell16, b1.x);
-    oj.x = fmaf((float)(h0 & 0xFFFFu), cell16, b0.y); oj.y = fmaf((float)(h1 & 0xFFFFu), cell16, b1.y);
+    oi.x = fmaf((float)xa, cell32, b0.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, b1.x);
+    oj.x = fmaf((float)xb, cell32, b0.y); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, b1.y);
+    xa += 2u * JIT_PHI_A; xb += 2u * JIT_PHI_B;                             // jitter lattice of the next pair
     const v2f d2 = pk_fma(oi, splat(T1) + oi, pk_fma(oj, splat(T2) + oj, splat(T0)));   // |ts|^2
     uint32_t m0 = 0xFFFFFFFFu, m1 = valid1 ? 0xFFFFFFFFu : 0u;             // min of candidate bit patterns
     v2f tr = splat(1.0f);
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const f3 up = normalize_clamped(crossf(right, ld));
       const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
       const float radius = (float)lg[8];
-      const float cell16 = n_sh > 1 ? (radius / (float)n_side) * (1.0f / 65536.0f) : 0.0f;
-      const uint32_t key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+      const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
+      const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
 #pragma unroll
       for (int k = 0; k < MAXS; ++k) {
         a_A[k] = a_B[k] = a_C[k] = 0.0f;
@@ -335,10 +336,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const float2* cells = s_cells + li * n_cells;
       float total;
       if (__any(need_lo))
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell16, tl, right, up,
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                    T0, T1, T2);
       else
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell16, tl, right, up,
+        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                     T0, T1, T2);
       const float T = total * inv_cells;
       const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                         // ray_tracer.py:543

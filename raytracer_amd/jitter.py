@@ -13,8 +13,8 @@ explicitly instead (BASELINE.json north_star: "the jitter is seeded and passed i
   the m-th hit of the batch.  The library regenerates that stream itself (same generator, same
   consumption order), which forces the reference's depth-first batch order on the device.
 
-Uniforms are multiples of 2**-16 in [0, 1): exactly representable in fp32 and fp64, so the fp64
-and fp32 kernels and the CPU oracle all see the same jitter values.
+Uniforms are fp32 values in [0, 1] (a uint32 converted to float32, times 2**-32), so the fp64 and
+fp32 kernels and the CPU oracle all see exactly the same jitter values.
 """
 from __future__ import annotations
 
@@ -25,7 +25,6 @@ import numpy as np
 JITTER_PIXEL_KEYED = 0   # mode B
 JITTER_NUMPY_STREAM = 1  # mode A
 
-_GOLDEN = np.uint32(0x9E3779B9)
 
 
 def lowbias32(x):
@@ -49,12 +48,22 @@ def light_key(seed, pixels, depth, light_index):
     return h
 
 
+_PHI_A, _PHI_B, _KB_XOR = np.uint32(0x9E3779B9), np.uint32(0x7F4A7C15), np.uint32(0x68E31DA4)
+
+
 def cell_uniforms(key, cell):
-    """(u_i, u_j) float64 for shadow-grid cell `cell = i*n + j` from the per-light key."""
+    """(u_i, u_j) float64 for shadow-grid cell `cell = i*n + j` from the per-light key.
+
+    Per-pixel rotated lattice: u = f32(k + (cell+1)*PHI) * 2**-32 with uint32 wrap-around, where
+    ka = key, kb = lowbias32(key ^ const) and f32() is the round-to-nearest uint32 -> float32
+    conversion (so every platform gets the same fp32 value; it can equal 1.0)."""
+    ka = np.asarray(key, dtype=np.uint32)
     with np.errstate(over="ignore"):
-        x = lowbias32(np.asarray(key, dtype=np.uint32) + np.uint32(cell + 1) * _GOLDEN)
-    u_i = (x >> np.uint32(16)).astype(np.float64) * 2.0 ** -16
-    u_j = (x & np.uint32(0xFFFF)).astype(np.float64) * 2.0 ** -16
+        kb = lowbias32(ka ^ _KB_XOR)
+        xa = ka + np.uint32(cell + 1) * _PHI_A
+        xb = kb + np.uint32(cell + 1) * _PHI_B
+    u_i = xa.astype(np.float32).astype(np.float64) * 2.0 ** -32
+    u_j = xb.astype(np.float32).astype(np.float64) * 2.0 ** -32
     return u_i, u_j
 
 
