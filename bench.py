@@ -9,7 +9,7 @@ A step = one frame: every rank renders its interleaved row blocks of the frame i
 The frame is fixed as N grows (strong scaling).  Rank 0 prints ONE JSON line.
 
 metric/value: Mrays/s, rays = radiance rays + shadow rays of the frame, whole job.
-roofline: the dominant kernel (k_shade_fast / k_shade_exact) — algorithmic flops of its launches
+roofline: the dominant kernel (k_shade_ls / k_shade_fast / k_shade_exact) — algorithmic flops of its launches
   (raytracer_amd/flops.py) / their summed duration, measured with HIP events on the
   stream the kernels run on (rt_stats, RT_FLAG_TIMING) during the timed steps.  The bound is the
   vector ALU (no MFMA-shaped work, HBM traffic is one framebuffer write), peak = 157.3 TFLOP/s fp32
@@ -106,11 +106,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # Rehearsal hooks for a one-GPU box: RT_BENCH_BACKEND=gloo RT_BENCH_ONE_DEVICE=1 run all ranks on
+    # cuda:0 and gather through host memory.  The real multi-GPU run uses nccl (= RCCL over xGMI).
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if os.environ.get("RT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
     n_shadow, max_depth = int(st.root_number_shadow_rays), int(st.max_recursions)
@@ -130,7 +138,7 @@ def main():
         gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
                   part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
         if world > 1:
-            gather_tiles(tile, tiling, rank, out=frame, scratch=scratch)
+            gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
 
     def barrier():
         if world > 1:
@@ -150,7 +158,8 @@ def main():
 
     # whole-job numbers: max time over ranks, rays summed over ranks
     last = all_stats[-1]
-    my = torch.tensor([elapsed, float(last.rays), float(last.hits), float(last.shadow_rays)], dtype=torch.float64, device=dev)
+    my = torch.tensor([elapsed, float(last.rays), float(last.hits), float(last.shadow_rays)], dtype=torch.float64,
+                      device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = my[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = my[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -180,7 +189,7 @@ def main():
                     traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": ("k_shade_small / k_shade_fast (fp32 shading)" if precision == "fp32" else "k_shade_exact"),
+            roofline = {"bound": "valu", "kernel": ("k_shade_ls (k_shade_fast for large scenes)" if precision == "fp32" else "k_shade_exact"),
                         "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
                         "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
@@ -195,7 +204,7 @@ def main():
             "data": "reference scene values (scenes/pool.txt etc. in-repo), pixel-keyed jitter seed 1234",
             "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
                        "shadow_rays": int(shadow), "row_blocks": args.block_rows,
-                       "parallelism": f"row-tiled x{world}" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@ class RowTiling:
         return len(self.rows[part])
 
 
-def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, scratch=None):
+def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, scratch=None, via_host=False):
     """Gather per-rank tiles (torch tensors [max_rows, W, C], rows beyond the rank's own count are
     padding) to `dst` and reassemble the frame [H, W, C] there.  Returns the frame on `dst`,
     None elsewhere.  `out` / `scratch` let the caller reuse buffers across frames."""
@@ -43,6 +43,20 @@ def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, 
             return out
         return frame
     assert tile.shape[0] == tiling.max_rows and tile.is_contiguous()
+    if via_host and tile.is_cuda:
+        # rehearsal path (gloo cannot gather device tensors): stage through host memory
+        host = tile.cpu()
+        if rank == dst:
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.gather(host, gather_list=parts, dst=dst, group=group)
+            if out is None:
+                out = torch.empty((tiling.height, tiling.width) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
+            for p in range(world):
+                idx = torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long)
+                out.index_copy_(0, idx, parts[p][: tiling.n_rows(p)].to(tile.device))
+            return out
+        dist.gather(host, gather_list=None, dst=dst, group=group)
+        return None
     if rank == dst:
         if scratch is None:
             scratch = [torch.empty_like(tile) for _ in range(world)]

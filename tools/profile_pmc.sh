@@ -5,7 +5,7 @@
 set -u
 WL=${1:-pool4k}
 OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift

@@ -20,7 +20,12 @@ def main():
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     per = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
+    newest = {}   # one CSV per pass directory: the most recent (gpurun merges runs into one tree)
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+        key = os.path.relpath(path, root).split(os.sep)[0]
+        if key not in newest or os.path.getmtime(path) > os.path.getmtime(newest[key]):
+            newest[key] = path
+    for path in newest.values():
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = row["Kernel_Name"].split("(")[0].replace("void ", "")
