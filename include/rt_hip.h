@@ -36,7 +36,8 @@ typedef enum rt_precision {
 } rt_precision;
 typedef enum rt_jitter_mode {
   RT_JITTER_PIXEL_KEYED = 0, /* u = hash(seed, pixel, depth, light, cell): pixels independent */
-  RT_JITTER_NUMPY_STREAM = 1 /* the MT19937 stream np.random.seed(seed) would feed the reference */
+  RT_JITTER_NUMPY_STREAM = 1 /* the MT19937 stream np.random.seed(seed) feeds the reference, consumed in the
+                                reference's order (ray_tracer.py:219-222); fp64, blocking calls only */
 } rt_jitter_mode;
 typedef enum rt_out_format { RT_OUT_F64 = 0, RT_OUT_F32 = 1, RT_OUT_U8 = 2 } rt_out_format;
 enum { RT_FLAG_ASYNC = 1,  /* device output only: return after enqueueing; call rt_sync() */

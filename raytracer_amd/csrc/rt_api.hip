@@ -19,6 +19,8 @@
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
 #include "rt_shade_ls.hpp"
+#include "rt_stream.hpp"
+#include <hipcub/hipcub.hpp>
 
 using namespace rt;
 
@@ -59,6 +61,10 @@ struct PendingFrame {
   std::vector<EventPair> events;
   int levels = 0, n_lights = 0, n_cells = 1, precision = 0;
   bool timing = false;
+  // numpy-stream mode: counted on the host per batch (depth-first batches, not levels)
+  bool stream = false;
+  int64_t s_rays = 0, s_hits = 0, s_queries = 0; int s_batches = 0;
+  int64_t s_level_rays[MAX_LEVELS] = {0}, s_level_hits[MAX_LEVELS] = {0};
 };
 
 struct rt_scene {
@@ -222,13 +228,17 @@ static int drain(rt_scene* s) {
     if (pf.user) {
       rt_stats st; std::memset(&st, 0, sizeof st);
       st.levels = pf.levels;
-      for (int l = 0; l < pf.levels; ++l) {
+      if (pf.stream) {
+        st.rays = pf.s_rays; st.hits = pf.s_hits; st.batches = pf.s_batches;
+        for (int l = 0; l < pf.levels; ++l) { st.level_rays[l] = pf.s_level_rays[l]; st.level_hits[l] = pf.s_level_hits[l]; }
+      }
+      for (int l = 0; l < pf.levels && !pf.stream; ++l) {
         st.level_rays[l] = c.n_rays[l]; st.level_hits[l] = c.n_hits[l];
         st.rays += c.n_rays[l]; st.hits += c.n_hits[l];
         if (c.n_rays[l]) st.batches++;
       }
       st.shadow_rays = st.hits * (int64_t)pf.n_lights * pf.n_cells;
-      st.segments = pf.precision == RT_FP64 ? (int64_t)c.queries - st.shadow_rays : -1;
+      st.segments = pf.precision == RT_FP64 ? (pf.stream ? pf.s_queries : (int64_t)c.queries) - st.shadow_rays : -1;
       if (pf.timing && !pf.events.empty()) {
         for (EventPair& ep : pf.events) {
           float ms = 0; hipEventElapsedTime(&ms, ep.a, ep.b);
@@ -347,6 +357,154 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
   return RT_OK;
 }
 
+// ------------------------------------------------- numpy-stream jitter (rt_stream.hpp) ---------
+// Legacy NumPy generator: np.random.seed(int) = init_genrand, np.random.random = genrand_res53.
+struct Mt19937 {
+  uint32_t mt[624]; int idx;
+  explicit Mt19937(uint32_t seed) {
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+  double uniform() { uint32_t a = next() >> 5, b = next() >> 6; return (a * 67108864.0 + b) / 9007199254740992.0; }
+};
+
+struct StreamBatch { double* buf = nullptr; uint32_t* pix = nullptr; uint32_t n = 0; int depth = 0; bool root = false; };
+
+static RayQueue batch_queue(const StreamBatch& b) {
+  RayQueue q; size_t c = b.n;
+  q.ox = b.buf; q.oy = b.buf + c; q.oz = b.buf + 2 * c; q.dx = b.buf + 3 * c; q.dy = b.buf + 4 * c; q.dz = b.buf + 5 * c;
+  q.wx = b.buf + 6 * c; q.wy = b.buf + 7 * c; q.wz = b.buf + 8 * c; q.pix = b.pix;
+  return q;
+}
+static hipError_t batch_alloc(StreamBatch* b, uint32_t n, int depth) {
+  b->n = n; b->depth = depth; b->root = false;
+  hipError_t e = hipMalloc(&b->buf, (size_t)std::max<uint32_t>(n, 1) * 9 * sizeof(double));
+  if (e != hipSuccess) return e;
+  return hipMalloc(&b->pix, (size_t)std::max<uint32_t>(n, 1) * sizeof(uint32_t));
+}
+static void batch_free(StreamBatch* b) { if (b->buf) hipFree(b->buf); if (b->pix) hipFree(b->pix); b->buf = nullptr; b->pix = nullptr; }
+
+static int render_stream(rt_scene* s, const DevCamera& cam, const FrameParams& fp, double* fb, PendingFrame* pf) {
+  hipStream_t st = s->stream;
+  const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
+  const int L = s->ds.nL, n_cells = fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1;
+  pf->stream = true;
+  HIPCHK(hipMemsetAsync(fb, 0, (size_t)P * 3 * sizeof(double), st));     // final_colors = zeros, ray_tracer.py:467
+  HIPCHK(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
+  Mt19937 rng(fp.seed);
+  std::vector<StreamBatch> stack;
+  { StreamBatch root; root.n = P; root.depth = 0; root.root = true; stack.push_back(root); }
+  std::vector<double> h_table;
+  struct Tmp { std::vector<void*> ptrs; ~Tmp() { for (void* p : ptrs) hipFree(p); } };
+  int rc = RT_OK;
+  auto grid = [](uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); };
+#define SCHK(call)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) { rc = fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); goto done; } \
+  } while (0)
+  while (!stack.empty()) {
+    StreamBatch b = stack.back(); stack.pop_back();
+    Tmp tmp;                                                            // per-batch device temporaries
+    if (!b.root) { tmp.ptrs.push_back(b.buf); tmp.ptrs.push_back(b.pix); }
+    if (b.depth > fp.max_depth || b.n == 0) continue;                   // ray_tracer.py:482-483
+    const uint32_t M = b.n;
+    pf->s_rays += M; pf->s_batches += 1; pf->s_level_rays[b.depth] += M;
+    auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.ptrs.push_back(p); return p; };
+    HitRec* rec = (HitRec*)dalloc((size_t)M * sizeof(HitRec));
+    uint32_t* flag = (uint32_t*)dalloc((size_t)M * 4);
+    uint32_t* off = (uint32_t*)dalloc((size_t)M * 4);
+    if (!rec || !flag || !off) { rc = fail(RT_ERR_NOMEM, "out of device memory (stream batch of %u rays)", M); goto done; }
+    RayQueue q = b.root ? RayQueue{} : batch_queue(b);
+    if (b.root) hipLaunchKernelGGL(k_sa_trace<true>, grid(M), dim3(BLOCK), 0, st, s->ds, cam, fp, q, M, rec, flag, fb);
+    else hipLaunchKernelGGL(k_sa_trace<false>, grid(M), dim3(BLOCK), 0, st, s->ds, cam, fp, q, M, rec, flag, fb);
+    size_t scan_bytes = 0;
+    SCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag, off, (int)M, st));
+    void* scan_tmp = dalloc(scan_bytes);
+    if (!scan_tmp) { rc = fail(RT_ERR_NOMEM, "out of device memory (scan)"); goto done; }
+    SCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, off, (int)M, st));
+    uint32_t last[2] = {0, 0};
+    SCHK(hipMemcpyAsync(&last[0], off + (M - 1), 4, hipMemcpyDeviceToHost, st));
+    SCHK(hipMemcpyAsync(&last[1], flag + (M - 1), 4, hipMemcpyDeviceToHost, st));
+    SCHK(hipStreamSynchronize(st));
+    const uint32_t H = last[0] + last[1];
+    if (H == 0) continue;                                               // ray_tracer.py:504-506
+    pf->s_hits += H; pf->s_level_hits[b.depth] += H;
+    HitRec* hits = (HitRec*)dalloc((size_t)H * sizeof(HitRec));
+    if (!hits) { rc = fail(RT_ERR_NOMEM, "out of device memory (hits)"); goto done; }
+    hipLaunchKernelGGL(k_sa_scatter_hits, grid(M), dim3(BLOCK), 0, st, rec, flag, off, M, hits);
+    // the next lights*cells*2*H uniforms of the stream, in draw order (ray_tracer.py:219-222)
+    double* d_table = nullptr;
+    if (fp.n_shadow > 1 && L > 0) {
+      const size_t n_tab = (size_t)L * n_cells * 2 * H;
+      if (n_tab * sizeof(double) > (size_t)8 << 30) { rc = fail(RT_ERR_INVALID, "numpy-stream jitter table of %.1f GB: use pixel-keyed jitter for frames this large", n_tab * 8.0 / (1 << 30)); goto done; }
+      h_table.resize(n_tab);
+      for (size_t i = 0; i < n_tab; ++i) h_table[i] = rng.uniform();
+      d_table = (double*)dalloc(n_tab * sizeof(double));
+      if (!d_table) { rc = fail(RT_ERR_NOMEM, "out of device memory (jitter table)"); goto done; }
+      SCHK(hipMemcpyAsync(d_table, h_table.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    StreamBatch tT, tR;                                                 // dense child temporaries, slot = hit rank
+    SCHK(batch_alloc(&tT, H, b.depth + 1)); tmp.ptrs.push_back(tT.buf); tmp.ptrs.push_back(tT.pix);
+    SCHK(batch_alloc(&tR, H, b.depth + 1)); tmp.ptrs.push_back(tR.buf); tmp.ptrs.push_back(tR.pix);
+    uint32_t* flagT = (uint32_t*)dalloc((size_t)H * 4); uint32_t* flagR = (uint32_t*)dalloc((size_t)H * 4);
+    uint32_t* offT = (uint32_t*)dalloc((size_t)H * 4); uint32_t* offR = (uint32_t*)dalloc((size_t)H * 4);
+    if (!flagT || !flagR || !offT || !offR) { rc = fail(RT_ERR_NOMEM, "out of device memory (child flags)"); goto done; }
+    if (b.root) hipLaunchKernelGGL(k_sa_shade<true>, grid(H), dim3(BLOCK), 0, st, s->ds, cam, fp, b.depth, q, hits, H, d_table, n_cells, batch_queue(tT), batch_queue(tR), flagT, flagR, fb, &s->d_counters->queries);
+    else hipLaunchKernelGGL(k_sa_shade<false>, grid(H), dim3(BLOCK), 0, st, s->ds, cam, fp, b.depth, q, hits, H, d_table, n_cells, batch_queue(tT), batch_queue(tR), flagT, flagR, fb, &s->d_counters->queries);
+    if (b.depth < fp.max_depth) {
+      size_t sb = 0;
+      SCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, flagT, offT, (int)H, st));
+      void* stmp = dalloc(sb);
+      if (!stmp) { rc = fail(RT_ERR_NOMEM, "out of device memory (scan)"); goto done; }
+      SCHK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, flagT, offT, (int)H, st));
+      SCHK(hipcub::DeviceScan::ExclusiveSum(stmp, sb, flagR, offR, (int)H, st));
+      uint32_t tail[4] = {0, 0, 0, 0};
+      SCHK(hipMemcpyAsync(&tail[0], offT + (H - 1), 4, hipMemcpyDeviceToHost, st));
+      SCHK(hipMemcpyAsync(&tail[1], flagT + (H - 1), 4, hipMemcpyDeviceToHost, st));
+      SCHK(hipMemcpyAsync(&tail[2], offR + (H - 1), 4, hipMemcpyDeviceToHost, st));
+      SCHK(hipMemcpyAsync(&tail[3], flagR + (H - 1), 4, hipMemcpyDeviceToHost, st));
+      SCHK(hipStreamSynchronize(st));
+      const uint32_t nT = tail[0] + tail[1], nR = tail[2] + tail[3];
+      if (nT) {                                                         // pushed first (ray_tracer.py:573)
+        StreamBatch c; SCHK(batch_alloc(&c, nT, b.depth + 1));
+        hipLaunchKernelGGL(k_sa_scatter_rays, grid(H), dim3(BLOCK), 0, st, batch_queue(tT), flagT, offT, H, batch_queue(c));
+        stack.push_back(c);
+      }
+      if (nR) {                                                         // pushed last => processed first (:589)
+        StreamBatch c; SCHK(batch_alloc(&c, nR, b.depth + 1));
+        hipLaunchKernelGGL(k_sa_scatter_rays, grid(H), dim3(BLOCK), 0, st, batch_queue(tR), flagR, offR, H, batch_queue(c));
+        stack.push_back(c);
+      }
+    }
+    SCHK(hipStreamSynchronize(st));                                     // temporaries are freed at scope exit
+    SCHK(hipGetLastError());
+  }
+done:
+#undef SCHK
+  hipStreamSynchronize(st);
+  for (StreamBatch& b : stack) if (!b.root) batch_free(&b);
+  if (rc == RT_OK) {
+    unsigned long long qv = 0;
+    if (hipMemcpy(&qv, &s->d_counters->queries, sizeof qv, hipMemcpyDeviceToHost) == hipSuccess) pf->s_queries = (int64_t)qv;
+    hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st);             // the pending-frame copy must read zeros
+  }
+  return rc;
+}
+
 extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
                          rt_stats* stats) {
   if (!s || !camera || !fr || !out) return fail(RT_ERR_INVALID, "rt_render: null pointer");
@@ -356,9 +514,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (fr->n_shadow < 0 || fr->n_shadow > 64) return fail(RT_ERR_INVALID, "rt_render: n_shadow %d outside [0,64]", fr->n_shadow);
   if (fr->precision != RT_FP64 && fr->precision != RT_FP32) return fail(RT_ERR_INVALID, "rt_render: unknown precision %d", fr->precision);
   if (fr->out_format < RT_OUT_F64 || fr->out_format > RT_OUT_U8) return fail(RT_ERR_INVALID, "rt_render: unknown out_format %d", fr->out_format);
-  if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM)
-    return fail(RT_ERR_INVALID, "rt_render: the numpy-stream jitter mode is not available in this build; use pixel-keyed jitter");
-  if (fr->jitter_mode != RT_JITTER_PIXEL_KEYED) return fail(RT_ERR_INVALID, "rt_render: unknown jitter mode %d", fr->jitter_mode);
+  if (fr->jitter_mode != RT_JITTER_PIXEL_KEYED && fr->jitter_mode != RT_JITTER_NUMPY_STREAM)
+    return fail(RT_ERR_INVALID, "rt_render: unknown jitter mode %d", fr->jitter_mode);
+  if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM && (fr->precision != RT_FP64 || (fr->flags & RT_FLAG_ASYNC)))
+    return fail(RT_ERR_INVALID, "rt_render: numpy-stream jitter needs precision fp64 and a blocking call");
   if ((fr->flags & RT_FLAG_ASYNC) && !out_is_device) return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_ASYNC needs a device output buffer");
   int32_t rows = 0;
   int rc = rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, &rows);
@@ -391,7 +550,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   DevCamera cam = to_dev_camera(camera);
 
   void* fb = direct ? out : s->d_fb;
-  rc = fb_is_double ? launch_frame<double>(s, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, cam, fp, fr, (float*)fb, &pf);
+  if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM) rc = render_stream(s, cam, fp, (double*)fb, &pf);
+  else rc = fb_is_double ? launch_frame<double>(s, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, cam, fp, fr, (float*)fb, &pf);
   if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
 
   if (!direct) {

@@ -200,9 +200,106 @@ __device__ __forceinline__ void spawn_children(bool active, int level, const Fra
 }
 
 // ------------------------------------------------------------------------- k_shade_exact -------
-// fp64 shading of a hit queue: literal restatement of ray_tracer.py:517-563 with
-// compute_soft_shadow_batch (:171-244) and compute_shadow_transmission_batch (:247-293) inlined per
-// hit.  Used by precision = RT_FP64.
+// Jitter sources of the fp64 shading code.  get(light, cell, &ui, &uj) returns the two uniforms of
+// one shadow-grid cell for the hit being shaded.
+struct JitPixelKeyed {          // mode B: pure function of (seed, pixel, depth, light, cell)
+  uint32_t seed, gpix, depth;
+  JitKey key;
+  __device__ __forceinline__ void begin_light(int li) { key = jit_light_key(seed, gpix, depth, (uint32_t)li); }
+  __device__ __forceinline__ void get(int, int cell, double* ui, double* uj) const {
+    *ui = (double)jit_ui(key, (uint32_t)cell); *uj = (double)jit_uj(key, (uint32_t)cell);
+  }
+};
+struct JitTable {               // mode A: table[((light*cells + cell)*2 + axis)*H + h] drawn from the NumPy stream
+  const double* tab; size_t H, h; int n_cells;
+  __device__ __forceinline__ void begin_light(int) {}
+  __device__ __forceinline__ void get(int li, int cell, double* ui, double* uj) const {
+    const size_t base = ((size_t)li * n_cells + cell) * 2;
+    *ui = tab[base * H + h]; *uj = tab[(base + 1) * H + h];
+  }
+};
+
+struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading result of one hit
+
+// Literal fp64 restatement of ray_tracer.py:517-563 for one hit, with compute_soft_shadow_batch
+// (:171-244) and compute_shadow_transmission_batch (:247-293) inlined.  c = (diffuse+specular)*(1-transparency).
+template <typename JIT>
+__device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Prim* __restrict__ P, const RayIn& r,
+                                                    const HitRec& hr, int n_sh, JIT& jit, int* queries) {
+  ExactHit out;
+  const Prim& pr = P[hr.prim];
+  const double t = hr.t;
+  const d3 n = prim_normal(pr, r.o, r.d, t);
+  const d3 hp = mk3(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);      // :517
+  const double* mat = sc.mats + MAT_STRIDE * pr.mat;
+  d3 v = mk3(r.o.x - hp.x, r.o.y - hp.y, r.o.z - hp.z);                            // :519
+  double vn = norm3(v); if (vn < EPS) vn = EPS;
+  v = mk3(v.x / vn, v.y / vn, v.z / vn);
+  const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);          // :538
+  double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+  for (int li = 0; li < sc.nL; ++li) {                                             // :526
+    const double* lg = sc.lights + LIGHT_STRIDE * li;
+    const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+    double T;
+    if (n_sh <= 1) {                                                               // :184-196
+      d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
+      double dist = norm3(tl);
+      d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
+      d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries);
+    } else {
+      d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
+      double ldist = norm3(tl);
+      d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+      d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);                  // :202-205
+      d3 right = cross3(ld, ref);                                                  // :207-209
+      double rn = norm3(right); if (rn < EPS) rn = EPS;
+      right = mk3(right.x / rn, right.y / rn, right.z / rn);
+      d3 up = cross3(right, ld);                                                   // :211-213
+      double un = norm3(up); if (un < EPS) un = EPS;
+      up = mk3(up.x / un, up.y / un, up.z / un);
+      const double radius = lg[8];
+      const double cell = radius / n_sh;                                           // :215
+      jit.begin_light(li);
+      double total = 0.0;
+      for (int i = 0; i < n_sh; ++i)
+        for (int j = 0; j < n_sh; ++j) {                                           // :219-241
+          double ui, uj;
+          jit.get(li, i * n_sh + j, &ui, &uj);
+          double oi = -radius / 2 + cell * (i + ui);
+          double oj = -radius / 2 + cell * (j + uj);
+          d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,
+                      (Lp.z + oi * right.z) + oj * up.z);
+          d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+          double dist = norm3(ts);
+          d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
+          d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries);
+        }
+      T = total / (double)(n_sh * n_sh);                                           // :243
+    }
+    double I = (1 - lg[7]) + lg[7] * T;                                            // :543
+    d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
+    double ldist = norm3(tl);
+    d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+    d3 ml = mk3(-l.x, -l.y, -l.z);
+    double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
+    double s1 = I * ndl;
+    dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
+    double dn = dot3(ml, n);                                                       // :549
+    d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
+    double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
+    double s2 = I * pow(rdv, mat[9]);                                              // :555-556
+    spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
+    spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
+  }
+  const double one_m = 1 - mat[10];                                                // :562
+  out.hp = hp; out.n = n; out.mat = mat;
+  out.c[0] = (dif[0] + spc[0]) * one_m; out.c[1] = (dif[1] + spc[1]) * one_m; out.c[2] = (dif[2] + spc[2]) * one_m;
+  return out;
+}
+
+// fp64 shading of a hit queue (precision = RT_FP64, pixel-keyed jitter).
 template <typename FB, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                        RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
@@ -212,7 +309,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t lane = __lane_id();
-  const int n_sh = fp.n_shadow;
   for (;;) {
     uint32_t base = grab64(&C->work_shade[level]);
     if (base >= count) break;
@@ -222,79 +318,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
     const double* mat = sc.mats;
     r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
     if (active) {
-      HitRec hr = hits[h];
+      const HitRec hr = hits[h];
       r = load_ray(level, hr.slot, cam, fp.rs, q);
-      const Prim& pr = P[hr.prim];
-      const double t = hr.t;
-      n = prim_normal(pr, r.o, r.d, t);
-      hp = mk3(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);              // :517
-      mat = sc.mats + MAT_STRIDE * pr.mat;
-      d3 v = mk3(r.o.x - hp.x, r.o.y - hp.y, r.o.z - hp.z);                            // :519
-      double vn = norm3(v); if (vn < EPS) vn = EPS;
-      v = mk3(v.x / vn, v.y / vn, v.z / vn);
-      const uint32_t gpix = global_pixel(fp.rs, r.lp);
-      const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);          // :538
-      double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+      JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = global_pixel(fp.rs, r.lp); jit.depth = (uint32_t)level;
       int queries = 0;
-      for (int li = 0; li < sc.nL; ++li) {                                             // :526
-        const double* lg = sc.lights + LIGHT_STRIDE * li;
-        const d3 Lp = mk3(lg[0], lg[1], lg[2]);
-        double T;
-        if (n_sh <= 1) {                                                               // :184-196
-          d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
-          double dist = norm3(tl);
-          d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
-          d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, &queries);
-        } else {
-          d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
-          double ldist = norm3(tl);
-          d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
-          d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);                  // :202-205
-          d3 right = cross3(ld, ref);                                                  // :207-209
-          double rn = norm3(right); if (rn < EPS) rn = EPS;
-          right = mk3(right.x / rn, right.y / rn, right.z / rn);
-          d3 up = cross3(right, ld);                                                   // :211-213
-          double un = norm3(up); if (un < EPS) un = EPS;
-          up = mk3(up.x / un, up.y / un, up.z / un);
-          const double radius = lg[8];
-          const double cell = radius / n_sh;                                           // :215
-          const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
-          double total = 0.0;
-          for (int i = 0; i < n_sh; ++i)
-            for (int j = 0; j < n_sh; ++j) {                                           // :219-241
-              double ui = (double)jit_ui(key, (uint32_t)(i * n_sh + j));
-              double uj = (double)jit_uj(key, (uint32_t)(i * n_sh + j));
-              double oi = -radius / 2 + cell * (i + ui);
-              double oj = -radius / 2 + cell * (j + uj);
-              d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,
-                          (Lp.z + oi * right.z) + oj * up.z);
-              d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
-              double dist = norm3(ts);
-              d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
-              d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-              total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, &queries);
-            }
-          T = total / (double)(n_sh * n_sh);                                           // :243
-        }
-        double I = (1 - lg[7]) + lg[7] * T;                                            // :543
-        d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
-        double ldist = norm3(tl);
-        d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
-        d3 ml = mk3(-l.x, -l.y, -l.z);
-        double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
-        double s1 = I * ndl;
-        dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
-        double dn = dot3(ml, n);                                                       // :549
-        d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
-        double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
-        double s2 = I * pow(rdv, mat[9]);                                              // :555-556
-        spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
-        spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
-      }
-      double one_m = 1 - mat[10];                                                      // :562-563
-      fb_put(fb, level == 0, r.lp, r.w.x * ((dif[0] + spc[0]) * one_m), r.w.y * ((dif[1] + spc[1]) * one_m),
-             r.w.z * ((dif[2] + spc[2]) * one_m));
+      const ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries);
+      hp = e.hp; n = e.n; mat = e.mat;
+      fb_put(fb, level == 0, r.lp, r.w.x * e.c[0], r.w.y * e.c[1], r.w.z * e.c[2]);      // :563
       atomicAdd(&C->queries, (unsigned long long)queries);
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C);

@@ -109,6 +109,32 @@ def test_fp64_image_matches_reference_golden(rt, oracle, name):
 
 
 @pytest.mark.parametrize("name", IMAGE_CASES)
+def test_fp64_numpy_stream_jitter_matches_unpatched_reference(rt, oracle, name):
+    """Mode A: the GPU consumes the same MT19937 stream, in the same order, as
+    `np.random.seed(1234); render_vectorized(...)` of the UNMODIFIED reference (golden image_A)."""
+    from raytracer_amd import load_scene
+    g = load_golden(name)
+    W, H = int(g["width"]), int(g["height"])
+    cam, st, mats, surfs, lights = load_scene(scene_path(str(g["scene"])), int(g["n_shadow"]), int(g["max_depth"]))
+    stats = {}
+    img = rt.render_hip(cam, st, mats, surfs, lights, W, H, precision="fp64", jitter=("numpy", int(g["seed"])),
+                        stats=stats, verbose=False)
+    assert rel_err(img, g["image_A"]).max() < 1e-9
+    o_img, o_stats = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("numpy", int(g["seed"])), return_stats=True)
+    assert rel_err(img, o_img).max() < 1e-12
+    for k in ("rays", "hits", "shadow_rays", "segments", "batches"):
+        assert stats[k] == o_stats[k], k
+    assert stats["rays"] == int(g["rays_A"])
+
+
+def test_numpy_stream_jitter_rejects_fp32(rt):
+    from raytracer_amd import load_scene, _lib
+    cam, st, mats, surfs, lights = load_scene(scene_path("pool.txt"), 2, 1)
+    with pytest.raises(_lib.RtError):
+        rt.render_hip(cam, st, mats, surfs, lights, 16, 16, precision="fp32", jitter=("numpy", 1), verbose=False)
+
+
+@pytest.mark.parametrize("name", IMAGE_CASES)
 def test_fp32_image_within_one_8bit_level(rt, name):
     from raytracer_amd import load_scene
     g = load_golden(name)
@@ -171,6 +197,21 @@ def test_error_paths(rt):
     surfs[0].material_index = 42                                       # reference: IndexError (ray_tracer.py:518)
     with pytest.raises(IndexError):
         GpuScene.from_objects(mats, surfs, lights, st.background_color)
+
+
+def test_original_1080p_fp64_numpy_stream_vs_oracle(rt, oracle):
+    """BASELINE config 2 with the reference's own jitter stream (np.random.seed(1234)) at full size."""
+    from raytracer_amd import load_scene
+    W, H = 1920, 1080
+    cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"))
+    stats = {}
+    img = rt.render_hip(cam, st, mats, surfs, lights, W, H, precision="fp64", jitter=("numpy", 1234), stats=stats, verbose=False)
+    o_img, o_stats = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("numpy", 1234), return_stats=True)
+    err = rel_err(img, o_img)
+    print(f"original 1080p fp64 numpy-stream: max rel err {err.max():.3e}; {stats['batches']} batches")
+    assert err.max() < 1e-9
+    for k in ("rays", "hits", "shadow_rays", "segments", "batches"):
+        assert stats[k] == o_stats[k]
 
 
 def test_original_1080p_fp64_vs_oracle(rt, oracle):
