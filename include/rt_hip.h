@@ -25,7 +25,7 @@ typedef enum rt_status {
   RT_ERR_INVALID = -1,        /* bad argument (null pointer, negative size, unknown enum, ...) */
   RT_ERR_HIP = -2,            /* a HIP runtime call failed; message has hipGetErrorString */
   RT_ERR_NOMEM = -3,          /* device or host allocation failed */
-  RT_ERR_QUEUE_OVERFLOW = -4, /* a bounce queue overflowed: render fewer rows per call (row sets) */
+  RT_ERR_QUEUE_OVERFLOW = -4, /* a bounce queue overflowed; blocking rt_render calls grow the queues and retry themselves */
   RT_ERR_NO_DEVICE = -5
 } rt_status;
 

@@ -77,6 +77,8 @@ struct rt_scene {
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
+  size_t min_queue = 0;          // queue capacity requested after an overflow (rays per level)
+  size_t overflow_need = 0;      // largest level size seen by the last overflowed frame
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
   void* d_out = nullptr;         // conversion / staging target
   HitRec* d_hits = nullptr;
@@ -224,7 +226,13 @@ static int drain(rt_scene* s) {
     PendingFrame pf = std::move(s->pending.front());
     s->pending.pop_front();
     const Counters& c = *pf.h_counters;
-    if (c.overflow) rc = fail(RT_ERR_QUEUE_OVERFLOW, "bounce queue overflow: render fewer rows per call");
+    if (c.overflow) {
+      size_t need = 0;
+      for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
+      s->overflow_need = need;
+      rc = fail(RT_ERR_QUEUE_OVERFLOW, "bounce queue overflow (a level holds >= %zu rays, capacity %zu): a blocking "
+                "rt_render call grows the queues and retries by itself", need, s->cap_queue);
+    }
     if (pf.user) {
       rt_stats st; std::memset(&st, 0, sizeof st);
       st.levels = pf.levels;
@@ -263,12 +271,14 @@ extern "C" int rt_sync(rt_scene* s) {
 }
 
 static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out) {
-  if (pixels > s->cap_pixels) {
+  const size_t want_q = std::max<size_t>(2 * pixels + 1024, s->min_queue);
+  if (pixels > s->cap_pixels || want_q > s->cap_queue) {
+    pixels = std::max(pixels, s->cap_pixels);
     int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
     void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
     free_workspace(s);
     s->d_out = keep_out; s->cap_out = keep_cap;
-    size_t q = 2 * pixels + 1024;
+    size_t q = std::max<size_t>(2 * pixels + 1024, s->min_queue);
     if (q > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
     HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_hits, q * sizeof(HitRec)));
@@ -505,9 +515,26 @@ done:
   return rc;
 }
 
+static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
+                         rt_stats* stats);
+
 extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
                          rt_stats* stats) {
   if (!s || !camera || !fr || !out) return fail(RT_ERR_INVALID, "rt_render: null pointer");
+  std::lock_guard<std::mutex> lk(s->mu);
+  int rc = RT_OK;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    rc = render_locked(s, camera, fr, out, out_is_device, stats);
+    if (rc != RT_ERR_QUEUE_OVERFLOW || (fr->flags & RT_FLAG_ASYNC)) break;
+    // A level outgrew the queues (more than ~2 live rays per pixel).  Levels below the truncated one
+    // were undercounted, so grow generously and render the frame again (rendering is deterministic).
+    s->min_queue = std::max(s->overflow_need + s->overflow_need / 4, 2 * s->cap_queue);
+  }
+  return rc;
+}
+
+static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
+                         rt_stats* stats) {
   if (fr->width <= 0 || fr->height <= 0) return fail(RT_ERR_INVALID, "rt_render: bad image size %dx%d", fr->width, fr->height);
   if (fr->block_rows <= 0) return fail(RT_ERR_INVALID, "rt_render: block_rows must be >= 1");
   if (fr->max_depth < 0 || fr->max_depth + 1 > MAX_LEVELS) return fail(RT_ERR_INVALID, "rt_render: max_depth %d outside [0,%d]", fr->max_depth, MAX_LEVELS - 1);
@@ -523,7 +550,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   int rc = rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, &rows);
   if (rc != RT_OK) return rc;
 
-  std::lock_guard<std::mutex> lk(s->mu);
   HIPCHK(hipSetDevice(s->device));
   const size_t pixels = (size_t)rows * fr->width, nval = pixels * 3;
   if (pixels == 0) { if (stats) std::memset(stats, 0, sizeof *stats); return RT_OK; }
