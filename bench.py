@@ -99,7 +99,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import _lib
-    from raytracer_amd.dist import RowTiling, cache_row_indices, gather_tiles
+    from raytracer_amd.dist import RowTiling, cache_row_indices, gather_tiles, new_scratch
     from raytracer_amd.flops import shade_kernel_flops, flops_per_query
     from raytracer_amd.packing import pack_scene
     from raytracer_amd.render import GpuScene
@@ -131,7 +131,7 @@ def main():
     dtype = torch.float32 if precision == "fp32" else torch.float64
     tile = torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev)
     frame = torch.empty((H, W, 3), dtype=dtype, device=dev) if (world > 1 and rank == 0) else None
-    scratch = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    scratch = new_scratch(tile, world) if (world > 1 and rank == 0) else None
     flags = _lib.RT_FLAG_ASYNC | (0 if args.no_timing else _lib.RT_FLAG_TIMING)
 
     def step(stats):

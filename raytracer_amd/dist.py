@@ -59,24 +59,44 @@ def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, 
         return None
     if rank == dst:
         if scratch is None:
-            scratch = [torch.empty_like(tile) for _ in range(world)]
+            scratch = new_scratch(tile, world)
         dist.gather(tile, gather_list=scratch, dst=dst, group=group)
         if out is None:
             out = torch.empty((tiling.height, tiling.width) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
+        base = getattr(scratch[0], "_rt_stack", None)
+        perm = getattr(tiling, "_perm", None)
+        if perm is not None and base is not None and base.shape[0] == world * tiling.max_rows:
+            # all tiles live in one allocation: de-interleave the frame with ONE gather kernel
+            torch.index_select(base, 0, perm, out=out)
+            return out
         for p in range(world):
-            idx = torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long) if not hasattr(tiling, "_idx") else None
-            if idx is None:
-                idx = tiling._idx[p]
+            idx = tiling._idx[p] if hasattr(tiling, "_idx") else torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long)
             out.index_copy_(0, idx, scratch[p][: tiling.n_rows(p)])
         return out
     dist.gather(tile, gather_list=None, dst=dst, group=group)
     return None
 
 
+def new_scratch(tile, world):
+    """Receive buffers of the gather root: `world` tiles carved out of ONE allocation, so that the
+    frame can be reassembled with a single index_select (see cache_row_indices)."""
+    import torch
+    base = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+    parts = list(base.split(tile.shape[0], dim=0))
+    for p in parts:
+        p._rt_stack = base
+    return parts
+
+
 def cache_row_indices(tiling: RowTiling, device):
-    """Put the per-part row index tensors on `device` once (avoids a host->device copy per frame)."""
+    """Put the row index tensors on `device` once (avoids a host->device copy per frame):
+    `_idx[p]` = image rows of part p; `_perm[y]` = position of image row y in the stacked tiles."""
     import torch
     tiling._idx = [torch.as_tensor(r, device=device, dtype=torch.long) for r in tiling.rows]
+    perm = np.empty(tiling.height, dtype=np.int64)
+    for p, rows in enumerate(tiling.rows):
+        perm[np.asarray(rows, dtype=np.int64)] = p * tiling.max_rows + np.arange(len(rows), dtype=np.int64)
+    tiling._perm = torch.as_tensor(perm, device=device)
     return tiling
 
 

@@ -45,12 +45,12 @@ def _worker(rank, world, port, W, H, block_rows, result_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W,H,block_rows", [(40, 30, 4), (33, 21, 8)])
-def test_two_rank_tiled_render_equals_full_frame(tmp_path, oracle, W, H, block_rows):
+@pytest.mark.parametrize("world,W,H,block_rows", [(2, 40, 30, 4), (2, 33, 21, 8), (3, 24, 22, 4)])
+def test_tiled_render_on_ranks_equals_full_frame(tmp_path, oracle, world, W, H, block_rows):
     import torch.multiprocessing as mp
     from raytracer_amd import load_scene
     result = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, _free_port(), W, H, block_rows, result), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, block_rows, result), nprocs=world, join=True)
     cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"), 2, 3)
     full = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 11))
     assert np.array_equal(np.load(result), full)
@@ -63,3 +63,22 @@ def test_row_tiling_partitions_all_rows():
         allrows = np.concatenate(t.rows)
         assert sorted(allrows) == list(range(H))
         assert t.max_rows == max(len(r) for r in t.rows)
+
+
+def test_stacked_tiles_permutation_matches_per_part_copy():
+    """The one-kernel de-interleave (index_select over the stacked receive buffers) and the
+    per-part index_copy fallback build the same frame."""
+    import torch
+    from raytracer_amd.dist import RowTiling, cache_row_indices, new_scratch
+    t = cache_row_indices(RowTiling(37, 5, 4, 3), "cpu")
+    tile = torch.zeros((t.max_rows, 5, 3), dtype=torch.float64)
+    parts = new_scratch(tile, 4)
+    for p in range(4):
+        parts[p].fill_(-1.0)
+        for k, y in enumerate(t.rows[p]):
+            parts[p][k] = float(y)
+    a = torch.index_select(parts[0]._rt_stack, 0, t._perm)
+    b = torch.empty_like(a)
+    for p in range(4):
+        b.index_copy_(0, t._idx[p], parts[p][: t.n_rows(p)])
+    assert torch.equal(a, b) and torch.equal(a[:, 0, 0], torch.arange(37, dtype=torch.float64))
