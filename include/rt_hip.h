@@ -41,7 +41,12 @@ typedef enum rt_jitter_mode {
 } rt_jitter_mode;
 typedef enum rt_out_format { RT_OUT_F64 = 0, RT_OUT_F32 = 1, RT_OUT_U8 = 2 } rt_out_format;
 enum { RT_FLAG_ASYNC = 1,  /* device output only: return after enqueueing; call rt_sync() */
-       RT_FLAG_TIMING = 2  /* bracket every kernel with HIP events, fill the *_ms stats fields */ };
+       RT_FLAG_TIMING = 2, /* bracket every kernel with HIP events, fill the *_ms stats fields */
+       RT_FLAG_SEQUENTIAL = 4 /* semantics of the reference's per-pixel recursive render() (ray_tracer.py:296-434)
+                                 instead of render_vectorized: plane accepts t == 1e-6 (infinite_plane.py:20), unbounded
+                                 shadow walk returning 0 below 1e-6 (:303-320), lights with intensity factor < 1e-6 skipped
+                                 (:347-348), specular only for r.v > 0 (:356), background*transparency where the transmitted
+                                 ray is not traced (:370-377).  Pixel-keyed jitter only; fp32 applies the last item only. */ };
 
 /*
  * Scene description, in scene-file (list) order — the order defines nearest-hit tie-breaking

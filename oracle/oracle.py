@@ -55,6 +55,7 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_render.restype = C.c_int
+        _lib.orc_render_sequential.restype = C.c_int
     return _lib
 
 
@@ -84,8 +85,9 @@ def _rays(origins, dirs):
 
 
 def render(camera, scene_settings, materials, surfaces, lights, width, height, *, jitter=("pixel", 1234),
-           block_rows=1, part=0, n_parts=1, return_stats=False):
-    """Oracle counterpart of the reference's render_vectorized (ray_tracer.py:437-604)."""
+           block_rows=1, part=0, n_parts=1, return_stats=False, sequential=False):
+    """Oracle counterpart of the reference's render_vectorized (ray_tracer.py:437-604), or with
+    sequential=True of its per-pixel recursive render (ray_tracer.py:398-434)."""
     from raytracer_amd.jitter import as_jitter
     jit = as_jitter(jitter)
     camera.setup(width / height)
@@ -95,7 +97,8 @@ def render(camera, scene_settings, materials, surfaces, lights, width, height, *
     nrows = len(rows_in_part(height, block_rows, part, n_parts))
     out = np.empty((nrows, width, 3), dtype=np.float64)
     st = Stats()
-    rc = lib().orc_render(C.byref(sc), C.byref(cam), int(width), int(height),
+    fn = lib().orc_render_sequential if sequential else lib().orc_render
+    rc = fn(C.byref(sc), C.byref(cam), int(width), int(height),
                           int(scene_settings.root_number_shadow_rays), int(scene_settings.max_recursions),
                           int(jit.mode), C.c_uint32(jit.seed & 0xFFFFFFFF), int(block_rows), int(part), int(n_parts),
                           _ptr(out), C.byref(st))

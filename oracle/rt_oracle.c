@@ -518,3 +518,176 @@ int orc_render(const orc_scene* sc, const orc_camera* cam, int W, int H, int n_s
   if (stats) *stats = st;
   return 0;
 }
+
+/* ------------------------------------------------- the sequential renderer (App. A.9) -------- */
+/*
+ * render(), ray_tracer.py:398-434, with trace_ray (:383-395), compute_color (:323-380),
+ * compute_soft_shadow (:130-168), compute_shadow_ray_transmission (:296-320) and the scalar
+ * intersect() methods (sphere.py:11-43, infinite_plane.py:11-24, cube.py:14-62) — the reference's
+ * per-pixel recursive renderer.  It differs from render_vectorized in (A.9): the plane accepts
+ * t == 1e-6; the shadow walk is unbounded and returns exactly 0.0 below EPS; a light whose
+ * intensity factor is < EPS is skipped; specular needs r.v > 0; `normalize` leaves vectors shorter
+ * than EPS unchanged; a transparent surface whose transmitted ray is not traced (depth cap, or
+ * transparency <= EPS) adds background*transparency; products are grouped as Python evaluates them.
+ * The scalar sphere and cube tests equal the batch ones (the cube's exit-face scan uses `> 1e-10`
+ * where the batch code uses `>=`; a measure-zero difference that is not mirrored).  The reference's
+ * scalar np.dot goes through BLAS, so results are pinned to <= 1e-9, not bit-exact.
+ * Jitter: mode A = scalar draws from the MT19937 stream in the reference's per-pixel depth-first
+ * order (u_i then u_j per cell; reflection subtree before transmission subtree; single-threaded);
+ * mode B = the pixel-keyed lattice with level = max_depth - depth.
+ */
+typedef struct {
+  const orc_scene* sc; int n_shadow, max_depth, jitter_mode; uint32_t seed; mt_state* mt; orc_stats st;
+} seq_ctx;
+
+static double seq_hit_surface(int type, const double* data, const double* o, const double* d, double* n) {
+  if (type != SURF_PLANE) return hit_surface(type, data, o, d, n);
+  double den = dot3(d, data);                                   /* infinite_plane.py:13-24 */
+  n[0] = n[1] = n[2] = 0.0;
+  if (fabs(den) < PAR_EPS) return INFINITY;
+  double t = (data[3] - dot3(o, data)) / den;
+  if (t < HIT_EPS || !(t == t)) return INFINITY;                /* `t < 1e-6` rejects: t == 1e-6 is a hit */
+  for (int k = 0; k < 3; ++k) n[k] = den > 0 ? -data[k] : data[k];
+  return t;
+}
+
+/* find_nearest_intersection, ray_tracer.py:94-109 */
+static double seq_nearest(const orc_scene* sc, const double* o, const double* d, double max_t, int* idx, double* n) {
+  double best = max_t; *idx = -1;
+  for (int s = 0; s < sc->n_surfaces; ++s) {
+    double ns[3];
+    double t = seq_hit_surface(sc->surf_type[s], sc->surf_data + 8 * s, o, d, ns);
+    if (t < best) { best = t; *idx = s; if (n) { n[0] = ns[0]; n[1] = ns[1]; n[2] = ns[2]; } }
+  }
+  return best;
+}
+
+/* compute_shadow_ray_transmission, ray_tracer.py:296-320 */
+static double seq_shadow(seq_ctx* c, const double* origin, const double* target, double max_distance) {
+  double dir[3], cur[3];
+  for (int k = 0; k < 3; ++k) { dir[k] = (target[k] - origin[k]) / max_distance; cur[k] = origin[k] + dir[k] * EPS; }
+  double remaining = max_distance - EPS, trans = 1.0;
+  int first = 1;
+  while (remaining > EPS) {
+    int idx; double t = seq_nearest(c->sc, cur, dir, remaining, &idx, 0);
+    if (!first) c->st.segments += 1;
+    first = 0;
+    if (idx < 0) break;
+    trans *= c->sc->materials[11 * c->sc->surf_material[idx] + 10];
+    if (trans < EPS) return 0.0;
+    for (int k = 0; k < 3; ++k) cur[k] = cur[k] + dir[k] * (t + EPS);
+    remaining -= (t + EPS);
+  }
+  return trans;
+}
+
+static void seq_normalize(double* v) {                          /* normalize, ray_tracer.py:17-21 */
+  double n = norm3(v);
+  if (n < EPS) return;
+  v[0] /= n; v[1] /= n; v[2] /= n;
+}
+
+/* compute_soft_shadow, ray_tracer.py:130-168 */
+static double seq_soft_shadow(seq_ctx* c, const double* p, const double* lg, uint32_t key) {
+  double tl[3] = {lg[0] - p[0], lg[1] - p[1], lg[2] - p[2]};
+  double dist = norm3(tl);
+  const int n = c->n_shadow;
+  c->st.shadow_rays += n <= 1 ? 1 : n * n;
+  if (n <= 1) return seq_shadow(c, p, lg, dist);
+  double ld[3] = {tl[0] / dist, tl[1] / dist, tl[2] / dist};
+  double ref[3] = {0, 0, 0}; if (fabs(ld[0]) < 0.9) ref[0] = 1.0; else ref[1] = 1.0;
+  double right[3], up[3];
+  cross3(ld, ref, right); seq_normalize(right);
+  cross3(right, ld, up); seq_normalize(up);
+  const double radius = lg[8], cell = radius / n;
+  double total = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double ui, uj;
+      if (c->jitter_mode == JIT_NUMPY_STREAM) { ui = mt_double(c->mt); uj = mt_double(c->mt); }
+      else jit_cell(key, (uint32_t)(i * n + j), &ui, &uj);
+      double oi = -radius / 2 + cell * (i + ui), oj = -radius / 2 + cell * (j + uj);
+      double sp[3], ts[3];
+      for (int k = 0; k < 3; ++k) { sp[k] = (lg[k] + right[k] * oi) + up[k] * oj; ts[k] = sp[k] - p[k]; }
+      total += seq_shadow(c, p, sp, norm3(ts));
+    }
+  return total / (double)(n * n);
+}
+
+/* trace_ray + compute_color, ray_tracer.py:323-395; depth counts down from max_depth */
+static void seq_trace(seq_ctx* c, const double* o, const double* d, int depth, uint32_t pixel, double* out) {
+  const orc_scene* sc = c->sc;
+  if (depth < 0) { for (int k = 0; k < 3; ++k) out[k] = sc->background[k]; return; }
+  int idx; double n[3];
+  c->st.rays += 1;
+  double t = seq_nearest(sc, o, d, INFINITY, &idx, n);
+  if (idx < 0) { for (int k = 0; k < 3; ++k) out[k] = sc->background[k]; return; }
+  c->st.hits += 1;
+  const double* mat = sc->materials + 11 * sc->surf_material[idx];
+  double hp[3], v[3], p[3];
+  for (int k = 0; k < 3; ++k) { hp[k] = o[k] + t * d[k]; v[k] = o[k] - hp[k]; p[k] = hp[k] + n[k] * EPS; }
+  seq_normalize(v);
+  double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+  for (int li = 0; li < sc->n_lights; ++li) {
+    const double* lg = sc->lights + 9 * li;
+    double l[3] = {lg[0] - hp[0], lg[1] - hp[1], lg[2] - hp[2]};
+    seq_normalize(l);
+    uint32_t key = jit_light_key(c->seed, pixel, (uint32_t)(c->max_depth - depth), (uint32_t)li);
+    double T = seq_soft_shadow(c, p, lg, key);
+    double I = (1 - lg[7]) + lg[7] * T;
+    if (I < EPS) continue;                                                        /* :347-348 */
+    double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;
+    for (int k = 0; k < 3; ++k) dif[k] += ((mat[k] * lg[3 + k]) * I) * ndl;       /* :351 */
+    double ml[3] = {-l[0], -l[1], -l[2]};
+    double dn = dot3(ml, n), r[3];
+    for (int k = 0; k < 3; ++k) r[k] = ml[k] - (2 * dn) * n[k];                   /* reflect :30-31 */
+    double rdv = dot3(r, v);
+    if (rdv > 0) {                                                                /* :356-359 */
+      double pw = pow(rdv, mat[9]);
+      for (int k = 0; k < 3; ++k) spc[k] += (((mat[3 + k] * lg[3 + k]) * lg[6]) * I) * pw;
+    }
+  }
+  double refl[3] = {0, 0, 0};
+  if (depth > 0 && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS)) {              /* :362-368 */
+    double dn = dot3(d, n), rd[3], ro[3], rc[3];
+    for (int k = 0; k < 3; ++k) { rd[k] = d[k] - (2 * dn) * n[k]; ro[k] = hp[k] + n[k] * EPS; }
+    seq_trace(c, ro, rd, depth - 1, pixel, rc);
+    for (int k = 0; k < 3; ++k) refl[k] = mat[6 + k] * rc[k];
+  }
+  double bg[3] = {sc->background[0], sc->background[1], sc->background[2]};
+  if (mat[10] > EPS && depth > 0) {                                               /* :371-374 */
+    double co[3];
+    for (int k = 0; k < 3; ++k) co[k] = hp[k] - n[k] * EPS;
+    seq_trace(c, co, d, depth - 1, pixel, bg);
+  }
+  for (int k = 0; k < 3; ++k) out[k] = (bg[k] * mat[10] + (dif[k] + spc[k]) * (1 - mat[10])) + refl[k];   /* :376-378 */
+}
+
+int orc_render_sequential(const orc_scene* sc, const orc_camera* cam, int W, int H, int n_shadow, int max_depth,
+                          int jitter_mode, uint32_t seed, int block_rows, int part, int n_parts,
+                          double* out, orc_stats* stats) {
+  if (W <= 0 || H <= 0 || block_rows <= 0) return -1;
+  int* rows = (int*)malloc((size_t)H * sizeof(int));
+  int nrows = 0;
+  for (int y = 0; y < H; ++y) if (row_in_set(y, block_rows, part, n_parts)) rows[nrows++] = y;
+  mt_state mt; mt_seed(&mt, seed);
+  orc_stats total = {0, 0, 0, 0, 0};
+  const int threads = jitter_mode == JIT_NUMPY_STREAM ? 1 : g_threads;           /* the stream is serial */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+  for (int lr = 0; lr < nrows; ++lr) {
+    seq_ctx c; c.sc = sc; c.n_shadow = n_shadow; c.max_depth = max_depth; c.jitter_mode = jitter_mode;
+    c.seed = seed; c.mt = &mt; memset(&c.st, 0, sizeof c.st);
+    const int y = rows[lr];
+    for (int x = 0; x < W; ++x) {
+      double d[3];
+      camera_dir(cam, W, H, x, y, d);                                             /* camera.py:30-44 */
+      seq_trace(&c, cam->pos, d, max_depth, (uint32_t)((long long)y * W + x), out + 3 * ((size_t)lr * W + x));
+    }
+#pragma omp critical
+    { total.rays += c.st.rays; total.hits += c.st.hits; total.shadow_rays += c.st.shadow_rays; total.segments += c.st.segments; }
+  }
+  total.batches = 0;
+  free(rows);
+  if (stats) *stats = total;
+  return 0;
+}

@@ -12,7 +12,7 @@ RT_OK = 0
 RT_ERR_QUEUE_OVERFLOW = -4
 RT_FP64, RT_FP32 = 0, 1
 RT_OUT_F64, RT_OUT_F32, RT_OUT_U8 = 0, 1, 2
-RT_FLAG_ASYNC, RT_FLAG_TIMING = 1, 2
+RT_FLAG_ASYNC, RT_FLAG_TIMING, RT_FLAG_SEQUENTIAL = 1, 2, 4
 RT_MAX_LEVELS = 32
 
 EXPORTS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream",

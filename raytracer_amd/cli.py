@@ -1,10 +1,13 @@
 """Command line front end with the reference's arguments (ray_tracer.py:615-644):
 
     python -m raytracer_amd.cli <scene_file> <output_image> [--width N] [--height N]
-                                [--precision fp64|fp32] [--seed S] [--device D]
+                                [--sequential] [--precision fp64|fp32] [--seed S]
+                                [--numpy-stream] [--device D]
 
-The renderer is the HIP backend (there is no CPU path here); the reference's `--sequential` flag
-has no counterpart.
+The renderer is the HIP backend (there is no CPU path here).  `--sequential` selects, like the
+reference's flag of that name (ray_tracer.py:620,633-637), the semantics of its per-pixel
+`render` — still computed on the GPU.  `--numpy-stream` reproduces `np.random.seed(S)` + the
+unmodified `render_vectorized` (fp64, single GPU).
 """
 import argparse
 
@@ -21,6 +24,8 @@ def main(argv=None):
     parser.add_argument("--height", type=int, default=500, help="Image height")
     parser.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
     parser.add_argument("--seed", type=int, default=1234, help="soft-shadow jitter seed (pixel-keyed)")
+    parser.add_argument("--sequential", action="store_true", help="semantics of the reference's sequential renderer")
+    parser.add_argument("--numpy-stream", action="store_true", help="jitter = the NumPy stream np.random.seed(seed) feeds the reference")
     parser.add_argument("--device", type=int, default=0)
     args = parser.parse_args(argv)
 
@@ -29,7 +34,8 @@ def main(argv=None):
     print(f"Scene loaded: {len(materials)} materials, {len(surfaces)} surfaces, {len(lights)} lights")
     print(f"Rendering {args.width}x{args.height} image...")
     image_array = render_hip(camera, scene_settings, materials, surfaces, lights, args.width, args.height,
-                             precision=args.precision, jitter=("pixel", args.seed), device=args.device)
+                             precision=args.precision, jitter=("numpy" if args.numpy_stream else "pixel", args.seed),
+                             device=args.device, sequential=args.sequential)
     save_image(image_array, args.output_image)
 
 

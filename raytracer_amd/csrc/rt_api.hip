@@ -20,6 +20,7 @@
 #include "rt_shade_fast.hpp"
 #include "rt_shade_ls.hpp"
 #include "rt_stream.hpp"
+#include <cmath>
 #include <hipcub/hipcub.hpp>
 
 using namespace rt;
@@ -545,6 +546,8 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
     return fail(RT_ERR_INVALID, "rt_render: unknown jitter mode %d", fr->jitter_mode);
   if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM && (fr->precision != RT_FP64 || (fr->flags & RT_FLAG_ASYNC)))
     return fail(RT_ERR_INVALID, "rt_render: numpy-stream jitter needs precision fp64 and a blocking call");
+  if ((fr->flags & RT_FLAG_SEQUENTIAL) && fr->jitter_mode != RT_JITTER_PIXEL_KEYED)
+    return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_SEQUENTIAL needs pixel-keyed jitter (the scalar stream order is per-pixel depth-first)");
   if ((fr->flags & RT_FLAG_ASYNC) && !out_is_device) return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_ASYNC needs a device output buffer");
   int32_t rows = 0;
   int rc = rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, &rows);
@@ -573,6 +576,8 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
   fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
   fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)s->cap_queue;
+  fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
+  fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
   DevCamera cam = to_dev_camera(camera);
 
   void* fb = direct ? out : s->d_fb;

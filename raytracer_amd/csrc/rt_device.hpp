@@ -101,12 +101,14 @@ __device__ __forceinline__ d3 sphere_normal(const Prim& s, d3 o, d3 d, double t)
 }
 
 // InfinitePlane.intersect_batch, surfaces/infinite_plane.py:30-49.
-__device__ __forceinline__ double plane_t(const Prim& p, d3 o, d3 d) {
+// `thr`: hit threshold.  The batch code accepts t > 1e-6 (infinite_plane.py:42); the scalar code of
+// the sequential renderer rejects t < 1e-6 (infinite_plane.py:20), i.e. accepts t > pred(1e-6).
+__device__ __forceinline__ double plane_t(const Prim& p, d3 o, d3 d, double thr = HIT_EPS) {
   d3 N = mk3(p.a[0], p.a[1], p.a[2]);
   double den = dot3(d, N);
   if (!(fabs(den) >= PAR_EPS)) return RT_INF;
   double t = (p.a[3] - dot3(o, N)) / den;
-  return (t > HIT_EPS) ? t : RT_INF;
+  return (t > thr) ? t : RT_INF;
 }
 __device__ __forceinline__ d3 plane_normal(const Prim& p, d3 d) {   // infinite_plane.py:51-56
   d3 N = mk3(p.a[0], p.a[1], p.a[2]);
@@ -167,7 +169,8 @@ __device__ __forceinline__ double box_hit(const Prim& b, d3 o, d3 d, d3* n_out) 
 // find_nearest_intersection_batch, ray_tracer.py:112-127.  The reference walks the surface list in
 // file order and replaces on a strict '<'; on the type-sorted records that is the lexicographic
 // minimum of (t, orig).  Returns t (INF = miss) and the *sorted* record index (-1 = miss).
-__device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out) {
+__device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
+                                          double plane_thr = HIT_EPS) {
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   int k = 0;
   for (int e = nS; k < e; ++k) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP; k < e; ++k) {
-    double t = plane_t(P[k], o, d);
+    double t = plane_t(P[k], o, d, plane_thr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
@@ -195,17 +198,23 @@ __device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
   d3 n; box_hit<true>(p, o, d, &n); return n;
 }
 
-// compute_shadow_transmission_batch, ray_tracer.py:247-293, for one ray.
+// compute_shadow_transmission_batch, ray_tracer.py:247-293, for one ray.  `seq`: the sequential
+// renderer's compute_shadow_ray_transmission instead (ray_tracer.py:296-320): walks while
+// remaining > EPS without the 20-step cap (SEQ_WALK_CAP only guards the GPU against a runaway
+// loop) and returns exactly 0 once the product drops below EPS.
+constexpr int SEQ_WALK_CAP = 1 << 16;
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
-                                              int* queries) {
+                                              int* queries, bool seq = false, double plane_thr = HIT_EPS) {
   double remaining = maxdist, trans = 1.0;
-  for (int step = 0; step < WALK_CAP; ++step) {
-    int k; double t = nearest(P, nS, nP, nB, o, d, &k);
+  const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
+  for (int step = 0; step < cap; ++step) {
+    if (seq && !(remaining > EPS)) break;                        // :303
+    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr);
     ++*queries;
     if (!((t < remaining) && k >= 0)) break;                     // :269-272, :290-291
     trans *= mats[MAT_STRIDE * P[k].mat + 10];                   // :276-279
-    if (trans < EPS) break;                                      // :281 (value kept)
+    if (trans < EPS) { if (seq) trans = 0.0; break; }            // :281 (value kept) / :314-315 (0.0)
     double adv = t + EPS;                                        // :287-288
     o = mk3(o.x + d.x * adv, o.y + d.y * adv, o.z + d.z * adv);
     remaining -= adv;

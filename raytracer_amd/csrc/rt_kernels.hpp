@@ -46,6 +46,8 @@ struct FrameParams {
   int32_t n_shadow, max_depth;
   uint32_t seed;
   uint32_t queue_cap;
+  uint32_t sequential;   // RT_FLAG_SEQUENTIAL: semantics of the reference's per-pixel render()
+  double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
 };
 
 __device__ __forceinline__ uint32_t global_pixel(const RowSet& rs, uint32_t lp) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
       int k = -1; double t = RT_INF;
       if (active) {
         RayIn r = load_ray(level, slot, cam, fp.rs, q);
-        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k);
+        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr);
         hit = k >= 0;
         if (level == 0) {
           // every pixel has exactly one level-0 ray: a plain store initialises the framebuffer
@@ -173,6 +175,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
 
 // Spawn the children of one shaded hit (ray_tracer.py:565-595) into the next level's queue.
 // Must be called convergently by every lane of the wave.
+// Sequential semantics (ray_tracer.py:370-377): when the transmitted ray of a hit is not traced (depth cap, or
+// transparency <= EPS) the surface still adds background * transparency.
+__device__ __forceinline__ bool seq_background_term(const FrameParams& fp, int level, const double* mat) {
+  return fp.sequential && mat[10] != 0.0 && !(level < fp.max_depth && mat[10] > EPS);
+}
+
 __device__ __forceinline__ void spawn_children(bool active, int level, const FrameParams& fp, const double* mat,
                                                const RayIn& r, d3 hp, d3 n, RayQueue& nq, Counters* C) {
   bool deeper = active && level < fp.max_depth;
@@ -225,7 +233,8 @@ struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading resu
 // (:171-244) and compute_shadow_transmission_batch (:247-293) inlined.  c = (diffuse+specular)*(1-transparency).
 template <typename JIT>
 __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Prim* __restrict__ P, const RayIn& r,
-                                                    const HitRec& hr, int n_sh, JIT& jit, int* queries) {
+                                                    const HitRec& hr, int n_sh, JIT& jit, int* queries,
+                                                    bool seq = false, double pthr = HIT_EPS) {
   ExactHit out;
   const Prim& pr = P[hr.prim];
   const double t = hr.t;
@@ -233,7 +242,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
   const d3 hp = mk3(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);      // :517
   const double* mat = sc.mats + MAT_STRIDE * pr.mat;
   d3 v = mk3(r.o.x - hp.x, r.o.y - hp.y, r.o.z - hp.z);                            // :519
-  double vn = norm3(v); if (vn < EPS) vn = EPS;
+  double vn = norm3(v); if (vn < EPS) vn = seq ? 1.0 : EPS;                        // normalize_batch :24-27 / normalize :17-21
   v = mk3(v.x / vn, v.y / vn, v.z / vn);
   const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);          // :538
   double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
@@ -246,7 +255,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
       double dist = norm3(tl);
       d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
       d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries);
+      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr);
     } else {
       d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
       double ldist = norm3(tl);
@@ -274,24 +283,37 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
           double dist = norm3(ts);
           d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
           d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries);
+          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr);
         }
       T = total / (double)(n_sh * n_sh);                                           // :243
     }
     double I = (1 - lg[7]) + lg[7] * T;                                            // :543
+    if (seq && I < EPS) continue;                                                  // sequential: :347-348
     d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
     double ldist = norm3(tl);
     d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
     d3 ml = mk3(-l.x, -l.y, -l.z);
     double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
-    double s1 = I * ndl;
-    dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
+    if (seq) {                                                                     // :351 ((Kd*Lc)*I)*ndl
+      dif[0] += ((mat[0] * lg[3]) * I) * ndl; dif[1] += ((mat[1] * lg[4]) * I) * ndl; dif[2] += ((mat[2] * lg[5]) * I) * ndl;
+    } else {
+      double s1 = I * ndl;
+      dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
+    }
     double dn = dot3(ml, n);                                                       // :549
     d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
     double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
-    double s2 = I * pow(rdv, mat[9]);                                              // :555-556
-    spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
-    spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
+    if (seq) {                                                                     // :356-359, only when r.v > 0
+      if (rdv > 0) {
+        const double pw = pow(rdv, mat[9]);
+        spc[0] += (((mat[3] * lg[3]) * lg[6]) * I) * pw; spc[1] += (((mat[4] * lg[4]) * lg[6]) * I) * pw;
+        spc[2] += (((mat[5] * lg[5]) * lg[6]) * I) * pw;
+      }
+    } else {
+      double s2 = I * pow(rdv, mat[9]);                                            // :555-556
+      spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
+      spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
+    }
   }
   const double one_m = 1 - mat[10];                                                // :562
   out.hp = hp; out.n = n; out.mat = mat;
@@ -322,8 +344,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
       r = load_ray(level, hr.slot, cam, fp.rs, q);
       JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = global_pixel(fp.rs, r.lp); jit.depth = (uint32_t)level;
       int queries = 0;
-      const ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries);
+      ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries, fp.sequential != 0, fp.plane_thr);
       hp = e.hp; n = e.n; mat = e.mat;
+      if (seq_background_term(fp, level, mat)) {                                          // :370-377
+        e.c[0] += sc.bg[0] * mat[10]; e.c[1] += sc.bg[1] * mat[10]; e.c[2] += sc.bg[2] * mat[10];
+      }
       fb_put(fb, level == 0, r.lp, r.w.x * e.c[0], r.w.y * e.c[1], r.w.z * e.c[2]);      // :563
       atomicAdd(&C->queries, (unsigned long long)queries);
     }

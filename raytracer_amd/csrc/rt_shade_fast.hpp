@@ -186,8 +186,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
         spc[2] = fmaf((float)mat[5] * (float)lg[5], s2, spc[2]);
       }
       const float one_m = 1.0f - (float)mat[10];
-      fb_put(fb, level == 0, r.lp, (float)r.w.x * ((dif[0] + spc[0]) * one_m), (float)r.w.y * ((dif[1] + spc[1]) * one_m),
-             (float)r.w.z * ((dif[2] + spc[2]) * one_m));
+      float bt[3] = {0.0f, 0.0f, 0.0f};
+      if (seq_background_term(fp, level, mat)) {                                            // ray_tracer.py:370-377
+        bt[0] = (float)(sc.bg[0] * mat[10]); bt[1] = (float)(sc.bg[1] * mat[10]); bt[2] = (float)(sc.bg[2] * mat[10]);
+      }
+      fb_put(fb, level == 0, r.lp, (float)r.w.x * ((dif[0] + spc[0]) * one_m + bt[0]),
+             (float)r.w.y * ((dif[1] + spc[1]) * one_m + bt[1]), (float)r.w.z * ((dif[2] + spc[2]) * one_m + bt[2]));
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C);
   }

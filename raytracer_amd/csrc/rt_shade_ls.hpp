@@ -363,7 +363,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     // ------------------------------------------------- phase 3: accumulate, spawn children -----
     if (active) {
       const float one_m = 1.0f - (float)mat[10];
-      const float c0 = wgt.x * ((dif0 + spc0) * one_m), c1 = wgt.y * ((dif1 + spc1) * one_m), c2 = wgt.z * ((dif2 + spc2) * one_m);
+      float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+      if (seq_background_term(fp, level, mat)) {                             // ray_tracer.py:370-377
+        b0 = (float)(sc.bg[0] * mat[10]); b1 = (float)(sc.bg[1] * mat[10]); b2 = (float)(sc.bg[2] * mat[10]);
+      }
+      const float c0 = wgt.x * ((dif0 + spc0) * one_m + b0), c1 = wgt.y * ((dif1 + spc1) * one_m + b1),
+                  c2 = wgt.z * ((dif2 + spc2) * one_m + b2);
       float* dst = fb + 3 * (size_t)lp;
       if (level == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
       else { atomicAdd(dst + 0, c0); atomicAdd(dst + 1, c1); atomicAdd(dst + 2, c2); }

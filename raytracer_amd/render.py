@@ -125,12 +125,14 @@ def _rays(origins, dirs):
 
 
 def render_hip(camera, scene_settings, materials, surfaces, lights, width, height, *,
-               precision="fp64", jitter=None, device=0, stats=None, verbose=True):
+               precision="fp64", jitter=None, device=0, stats=None, verbose=True, sequential=False):
     """Drop-in for the reference's render_vectorized: returns (height, width, 3) float64 unclipped
     linear radiance and, like the reference, calls camera.setup(width / height) first.
 
     Keyword-only extras: precision "fp64" (1e-9 relative parity) or "fp32" (fast mode, <= 1/255 per
-    8-bit channel); jitter = int seed | ("pixel", seed) | ("numpy", seed); stats = dict to fill.
+    8-bit channel); jitter = int seed | ("pixel", seed) | ("numpy", seed); stats = dict to fill;
+    sequential=True renders with the semantics of the reference's per-pixel `render`
+    (ray_tracer.py:398-434; differences listed at RT_FLAG_SEQUENTIAL in include/rt_hip.h).
     """
     t0 = time.time()
     camera.setup(width / height)
@@ -140,7 +142,8 @@ def render_hip(camera, scene_settings, materials, surfaces, lights, width, heigh
         print(f"Max depth: {max_depth}, Shadow rays: {n_shadow}x{n_shadow}={n_shadow * n_shadow} per light")
         print(f"HIP rendering {width}x{height} = {width * height} rays ({precision})...")
     with GpuScene.from_objects(materials, surfaces, lights, scene_settings.background_color, device) as gs:
-        img = gs.render(camera, width, height, n_shadow, max_depth, precision=precision, jitter=jitter)
+        img = gs.render(camera, width, height, n_shadow, max_depth, precision=precision, jitter=jitter,
+                        flags=_lib.RT_FLAG_SEQUENTIAL if sequential else 0)
         st = gs.last_stats
     if stats is not None:
         stats.update(st)
@@ -151,6 +154,11 @@ def render_hip(camera, scene_settings, materials, surfaces, lights, width, heigh
 
 
 render_vectorized = render_hip   # same name as the reference entry point
+
+
+def render(camera, scene_settings, materials, surfaces, lights, width, height, **kw):
+    """Counterpart of the reference's sequential `render` (ray_tracer.py:398-434) on the GPU."""
+    return render_hip(camera, scene_settings, materials, surfaces, lights, width, height, sequential=True, **kw)
 
 
 def nearest_hit(surfaces, origins, dirs, device=0):

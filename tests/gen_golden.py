@@ -72,6 +72,42 @@ def pixel_keyed_numpy(seed):
         np.random.random = real
 
 
+@contextlib.contextmanager
+def pixel_keyed_scalar(seed):
+    """Mode B for the reference's sequential render(): np.random.random() (scalar) is called twice per
+    shadow-grid cell from compute_soft_shadow (ray_tracer.py:156-157); key = (pixel, level, light, cell)
+    with level = max_depth - depth (the sequential renderer counts depth down)."""
+    jit = PixelKeyedJitter(seed)
+    real = np.random.random
+    state = {"axis": 0, "pair": None}
+
+    def fake():
+        f = sys._getframe(1)
+        assert f.f_code.co_name == "compute_soft_shadow", f.f_code.co_name
+        cc = f.f_back
+        assert cc.f_code.co_name == "compute_color", cc.f_code.co_name
+        i, j, n = f.f_locals["i"], f.f_locals["j"], f.f_locals["n_shadow_rays"]
+        light = f.f_locals["light"]
+        li = next(k for k, l in enumerate(cc.f_locals["lights"]) if l is light)
+        r = cc
+        while r.f_code.co_name != "render":
+            r = r.f_back
+        pixel = r.f_locals["y"] * r.f_locals["width"] + r.f_locals["x"]
+        level = r.f_locals["max_depth"] - cc.f_locals["depth"]
+        if state["axis"] == 0:
+            ui, uj = jit.uniforms(np.array([pixel]), level, li, i * n + j)
+            state["pair"] = (float(ui[0]), float(uj[0]))
+        u = state["pair"][state["axis"]]
+        state["axis"] ^= 1
+        return u
+
+    np.random.random = fake
+    try:
+        yield
+    finally:
+        np.random.random = real
+
+
 def ref_scene(path, n=None, depth=None):
     cam, st, objs = ref.parse_scene_file(path)
     if n is not None:
@@ -94,6 +130,16 @@ def ref_render(path, W, H, mode, seed, n=None, depth=None):
                 img = ref.render_vectorized(cam, st, mats, surfs, lights, W, H)
     rays = int(log.getvalue().rsplit("(", 1)[1].split()[0])
     return img, rays
+
+
+def ref_render_sequential(path, W, H, mode, seed, n=None, depth=None):
+    cam, st, mats, surfs, lights = ref_scene(path, n, depth)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if mode == "A":
+            np.random.seed(seed)
+            return ref.render(cam, st, mats, surfs, lights, W, H)
+        with pixel_keyed_scalar(seed):
+            return ref.render(cam, st, mats, surfs, lights, W, H)
 
 
 def save(name, **arrays):
@@ -121,6 +167,24 @@ def gen_images():
             img, rays = ref_render(path, W, H, mode, SEED, n, depth)
             out[f"image_{mode}"] = img
             out[f"rays_{mode}"] = np.array(rays)
+        cam, st, *_ = ref_scene(path, n, depth)
+        save(name, scene=np.array(scene), width=np.array(W), height=np.array(H),
+             n_shadow=np.array(st.root_number_shadow_rays), max_depth=np.array(st.max_recursions),
+             seed=np.array(SEED), **out)
+
+
+# ------------------------------------------- GS: the sequential renderer ------
+def gen_sequential():
+    cases = [
+        ("gs1_original_48x27", "original.txt", 48, 27, None, None),   # transparency, depth 5
+        ("gs2_pool_32", "pool.txt", 32, 32, 3, 2),
+        ("gs3_boxes_40x30", "boxes.txt", 40, 30, None, None),
+        ("gs4_original_d1_40x24", "original.txt", 40, 24, 2, 1),      # depth cap hit by transparent surfaces
+        ("gs5_original_n1_d0_32x18", "original.txt", 32, 18, 1, 0),   # one shadow ray, no recursion
+    ]
+    for name, scene, W, H, n, depth in cases:
+        path = os.path.join(ROOT, "scenes", scene)
+        out = {f"image_{mode}": ref_render_sequential(path, W, H, mode, SEED, n, depth) for mode in ("A", "B")}
         cam, st, *_ = ref_scene(path, n, depth)
         save(name, scene=np.array(scene), width=np.array(W), height=np.array(H),
              n_shadow=np.array(st.root_number_shadow_rays), max_depth=np.array(st.max_recursions),
@@ -264,7 +328,11 @@ def gen_camera():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if sys.argv[1:] == ["sequential"]:
+        gen_sequential()
+        sys.exit(0)
     gen_primitives()
     gen_shadow_walks()
     gen_camera()
     gen_images()
+    gen_sequential()

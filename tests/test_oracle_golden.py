@@ -111,3 +111,31 @@ def test_row_tiles_equal_full_frame(oracle):
                              block_rows=4, part=part, n_parts=3)
         out[rows_in_part(H, 4, part, 3)] = tile
     assert np.array_equal(out, full)
+
+
+# ------------------------------------------------- sequential renderer -------
+SEQ_CASES = ["gs1_original_48x27", "gs2_pool_32", "gs3_boxes_40x30", "gs4_original_d1_40x24", "gs5_original_n1_d0_32x18"]
+
+
+@pytest.mark.parametrize("name", SEQ_CASES)
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_sequential_oracle_matches_reference_render(oracle, name, mode):
+    """oracle.render(sequential=True) vs images of the reference's own per-pixel `render`
+    (ray_tracer.py:398-434): mode A = np.random.seed(1234) scalar stream, mode B = pixel-keyed.
+    The scalar code's np.dot goes through BLAS -> tolerance 1e-9 relative, not bit-exact."""
+    from raytracer_amd import load_scene
+    g = load_golden(name)
+    cam, st, mats, surfs, lights = load_scene(scene_path(str(g["scene"])), int(g["n_shadow"]), int(g["max_depth"]))
+    jit = ("numpy", int(g["seed"])) if mode == "A" else ("pixel", int(g["seed"]))
+    img = oracle.render(cam, st, mats, surfs, lights, int(g["width"]), int(g["height"]), jitter=jit, sequential=True)
+    assert rel_err(img, g["image_" + mode]).max() < 1e-9
+
+
+def test_sequential_and_vectorized_semantics_differ_where_expected(oracle):
+    """At the depth cap the sequential renderer adds background*transparency (ray_tracer.py:370-377),
+    the vectorized one nothing: the two oracles must differ on original.txt with max_depth 1."""
+    from raytracer_amd import load_scene
+    cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"), 2, 1)
+    a = oracle.render(cam, st, mats, surfs, lights, 40, 24, jitter=("pixel", 1234))
+    b = oracle.render(cam, st, mats, surfs, lights, 40, 24, jitter=("pixel", 1234), sequential=True)
+    assert np.abs(a - b).max() > 1e-3
