@@ -6,6 +6,7 @@ the hot path (`render_hip`) runs in hand-written HIP kernels behind the C-ABI of
 from .scene import (Camera, Light, Material, SceneSettings, Sphere, InfinitePlane, Cube,  # noqa: F401
                     parse_scene_file, parse_scene_text, separate_objects, load_scene)
 from .jitter import PixelKeyedJitter, NumpyStreamJitter  # noqa: F401
+from .scene_cache import load_packed, pack_scene_text  # noqa: F401
 
 __version__ = "0.1.0"
 
