@@ -53,6 +53,103 @@ extern "C" int rt_device_count(int* count) {
   return RT_OK;
 }
 
+// --------------------------------------------------------------- culling hierarchy (host) ------
+// Built once per scene for scenes that do not fit the LDS-staged brute-force kernels (n > LDS_PRIMS):
+// spheres and boxes are Morton-sorted by centre inside their type range (tie-breaking uses Prim::orig,
+// so the record order inside a type is free), then an 8-ary tree over the sorted order is emitted in
+// depth-first order with skip links (rt_device.hpp, BvhNode).  Bounds are spheres, inflated so that
+// rounding the double-precision geometry to fp32 can only make them larger.
+namespace {
+struct BoundD { double c[3], r; };
+
+BoundD prim_bound(const Prim& p) {
+  BoundD b;
+  if (p.type == RT_SPHERE) { for (int k = 0; k < 3; ++k) b.c[k] = p.a[k]; b.r = std::fabs(p.a[3]); }
+  else {                      // box: centre + half diagonal
+    double h2 = 0;
+    for (int k = 0; k < 3; ++k) { b.c[k] = 0.5 * (p.a[k] + p.a[3 + k]); double h = 0.5 * std::fabs(p.a[3 + k] - p.a[k]); h2 += h * h; }
+    b.r = std::sqrt(h2);
+  }
+  return b;
+}
+
+float4 to_float_bound(const BoundD& b) {
+  const double cmax = std::max(std::fabs(b.c[0]), std::max(std::fabs(b.c[1]), std::fabs(b.c[2])));
+  const double r = (b.r + 4.0 * 1.2e-7 * cmax) * (1.0 + 1e-6) + 1e-30;     // covers the centre's fp32 rounding
+  float rf = (float)r;
+  if ((double)rf < r) rf = std::nextafter(rf, INFINITY);
+  if (!(rf == rf) || std::isinf(rf)) rf = 3.0e38f;
+  return make_float4((float)b.c[0], (float)b.c[1], (float)b.c[2], rf);
+}
+
+uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+  v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v;
+}
+
+struct BvhBuilder {
+  const std::vector<Prim>& prims;
+  std::vector<BvhNode> nodes;
+  explicit BvhBuilder(const std::vector<Prim>& p) : prims(p) {}
+  // enclosing sphere of a set of spheres: centre of their common AABB, radius = max reach
+  static BoundD enclose(const std::vector<BoundD>& v) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (const BoundD& b : v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.c[k] - b.r); hi[k] = std::max(hi[k], b.c[k] + b.r); }
+    BoundD o; for (int k = 0; k < 3; ++k) o.c[k] = 0.5 * (lo[k] + hi[k]);
+    o.r = 0;
+    for (const BoundD& b : v) {
+      double d2 = 0; for (int k = 0; k < 3; ++k) d2 += (b.c[k] - o.c[k]) * (b.c[k] - o.c[k]);
+      o.r = std::max(o.r, std::sqrt(d2) + b.r);
+    }
+    return o;
+  }
+  BoundD build(int first, int count) {
+    const int idx = (int)nodes.size();
+    nodes.push_back(BvhNode{});
+    BoundD bound;
+    if (count <= 8) {
+      std::vector<BoundD> v; for (int i = 0; i < count; ++i) v.push_back(prim_bound(prims[first + i]));
+      bound = enclose(v);
+      nodes[idx].first = first; nodes[idx].count = count;
+    } else {
+      long long child = 8; while (child * 8 < count) child *= 8;     // largest power of 8 below count
+      std::vector<BoundD> v;
+      for (long long off = 0; off < count; off += child) v.push_back(build(first + (int)off, (int)std::min<long long>(child, count - off)));
+      bound = enclose(v);
+      nodes[idx].first = first; nodes[idx].count = 0;
+    }
+    const float4 f = to_float_bound(bound);
+    nodes[idx].cx = f.x; nodes[idx].cy = f.y; nodes[idx].cz = f.z; nodes[idx].r = f.w;
+    nodes[idx].skip = (int)nodes.size(); nodes[idx].pad = 0;
+    return bound;
+  }
+};
+
+// Morton order of the records [first, first+count) by bound centre (stable for equal codes).
+void morton_sort(std::vector<Prim>& prims, int first, int count) {
+  if (count <= 8) return;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < count; ++i) { BoundD b = prim_bound(prims[first + i]); for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.c[k]); hi[k] = std::max(hi[k], b.c[k]); } }
+  std::vector<std::pair<uint32_t, int>> key(count);
+  for (int i = 0; i < count; ++i) {
+    BoundD b = prim_bound(prims[first + i]);
+    uint32_t code = 0;
+    for (int k = 0; k < 3; ++k) {
+      double ext = hi[k] - lo[k];
+      double u = ext > 0 ? (b.c[k] - lo[k]) / ext : 0.0;
+      if (!(u >= 0)) u = 0;
+      if (u > 1) u = 1;
+      code |= spread10((uint32_t)(u * 1023.0)) << k;
+    }
+    key[i] = {code, i};
+  }
+  std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b) { return a.first < b.first; });
+  std::vector<Prim> tmp(count);
+  for (int i = 0; i < count; ++i) tmp[i] = prims[first + key[i].second];
+  std::copy(tmp.begin(), tmp.end(), prims.begin() + first);
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------- scene ---------
 struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 trace, 1 shade, 2 other
 
@@ -74,6 +171,7 @@ struct rt_scene {
   int num_cu = 256;
   DevScene ds{};
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
+  BvhNode* d_nodes = nullptr; float4* d_pbound = nullptr;   // culling hierarchy (large scenes only)
   bool all_opaque = true;
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
@@ -135,6 +233,24 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       prims.push_back(p);
       ++cnt[type];
     }
+  // large scenes: Morton order inside the sphere / box ranges + culling hierarchy (RT_ACCEL=0: brute force)
+  std::vector<BvhNode> nodes;
+  std::vector<float4> pbound;
+  {
+    const char* e = getenv("RT_ACCEL");
+    const bool want = !(e && e[0] == '0');
+    if (want && (int)prims.size() > LDS_PRIMS && cnt[0] + cnt[2] > 0) {
+      morton_sort(prims, 0, cnt[0]);
+      morton_sort(prims, cnt[0] + cnt[1], cnt[2]);
+      BvhBuilder bb(prims);
+      if (cnt[0] > 0) bb.build(0, cnt[0]);
+      if (cnt[2] > 0) bb.build(cnt[0] + cnt[1], cnt[2]);
+      nodes.swap(bb.nodes);
+      pbound.resize(prims.size());
+      for (size_t i = 0; i < prims.size(); ++i)
+        pbound[i] = prims[i].type == RT_PLANE ? make_float4(0, 0, 0, 3.0e38f) : to_float_bound(prim_bound(prims[i]));
+    }
+  }
   std::vector<double> mats((size_t)std::max(desc->n_materials, 1) * MAT_STRIDE, 0.0);
   for (int i = 0; i < desc->n_materials; ++i)
     for (int k = 0; k < 11; ++k) mats[(size_t)i * MAT_STRIDE + k] = desc->materials[(size_t)i * 11 + k];
@@ -166,7 +282,14 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (!prims.empty()) HIPCHK_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
   HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (!nodes.empty()) {
+    HIPCHK_S(hipMalloc(&s->d_nodes, nodes.size() * sizeof(BvhNode)));
+    HIPCHK_S(hipMalloc(&s->d_pbound, pbound.size() * sizeof(float4)));
+    HIPCHK_S(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMemcpy(s->d_pbound, pbound.data(), pbound.size() * sizeof(float4), hipMemcpyHostToDevice));
+  }
 #undef HIPCHK_S
+  s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.pad = 0;
   s->ds.prims = s->d_prims; s->ds.mats = s->d_mats; s->ds.lights = s->d_lights;
   s->ds.nS = cnt[0]; s->ds.nP = cnt[1]; s->ds.nB = cnt[2]; s->ds.n = (int)prims.size();
   s->ds.nM = desc->n_materials; s->ds.nL = desc->n_lights;
@@ -186,6 +309,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_prims) hipFree(s->d_prims);
   if (s->d_mats) hipFree(s->d_mats);
   if (s->d_lights) hipFree(s->d_lights);
+  if (s->d_nodes) hipFree(s->d_nodes);
+  if (s->d_pbound) hipFree(s->d_pbound);
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
   for (hipEvent_t e : s->event_pool) hipEventDestroy(e);

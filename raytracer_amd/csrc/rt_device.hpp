@@ -29,6 +29,26 @@ struct __attribute__((aligned(16))) Prim {
 };
 static_assert(sizeof(Prim) == 64, "Prim must be 64 bytes");
 
+// Conservative culling hierarchy for scenes too large for the brute-force loops (host-built in
+// rt_api.hip).  It never changes a result: a node / primitive is skipped only when
+// its bounding sphere (inflated for fp32 rounding) cannot be touched by the query, and every
+// surviving primitive goes through the same exact test as in the brute-force loop; ties are still
+// broken by (t, orig).  Nodes are stored in depth-first order with skip links, so a lane walks the
+// tree without a stack: hit -> next node, miss -> node.skip.  Leaves own <= 8 consecutive records
+// of ONE type (spheres and boxes are Morton-sorted inside their type range); planes are unbounded
+// and stay outside the tree (always tested).
+struct __attribute__((aligned(16))) BvhNode {
+  float cx, cy, cz, r;     // bounding sphere
+  int32_t first, count;    // leaf: records [first, first+count); inner node: count == 0
+  int32_t skip, pad;       // index of the next node when this one is missed
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
+struct Accel {
+  const BvhNode* nodes;    // nullptr / n_nodes == 0: no hierarchy (small scenes)
+  const float4* pbound;    // [n] bounding sphere of each record (planes: unused)
+  int32_t n_nodes, pad;
+};
+
 struct DevScene {
   const Prim* prims;      // device memory, type-sorted
   const double* mats;     // [nM][12]: diffuse rgb, specular rgb, reflection rgb, shininess, transparency, pad
@@ -36,6 +56,7 @@ struct DevScene {
   int32_t nS, nP, nB, n;  // counts per type and total
   int32_t nM, nL;
   double bg[3];
+  Accel ac;
 };
 constexpr int MAT_STRIDE = 12;
 constexpr int LIGHT_STRIDE = 12;
@@ -169,8 +190,11 @@ __device__ __forceinline__ double box_hit(const Prim& b, d3 o, d3 d, d3* n_out) 
 // find_nearest_intersection_batch, ray_tracer.py:112-127.  The reference walks the surface list in
 // file order and replaces on a strict '<'; on the type-sorted records that is the lexicographic
 // minimum of (t, orig).  Returns t (INF = miss) and the *sorted* record index (-1 = miss).
+__device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
+                                                int* k_out, double plane_thr);
 __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
-                                          double plane_thr = HIT_EPS) {
+                                          double plane_thr = HIT_EPS, const Accel* ac = nullptr) {
+  if (ac != nullptr && ac->n_nodes > 0) return nearest_accel(P, nS, nP, *ac, o, d, k_out, plane_thr);
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   int k = 0;
   for (int e = nS; k < e; ++k) {
@@ -192,6 +216,58 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
   return best;
 }
 
+// Does the ray (origin of, UNIT direction uf, fp32 copies) possibly touch the sphere (c, r) at a
+// parameter <= tmax_u (unit-length parameter, already rounded up)?  Conservative: the slack covers
+// the fp32 rounding of the ray, of the bound and of this arithmetic by two orders of magnitude.
+__device__ __forceinline__ bool ray_may_touch(float cx, float cy, float cz, float r, float ofx, float ofy, float ofz,
+                                              float ux, float uy, float uz, float tmax_u) {
+  const float vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
+  const float rs = r + 2e-5f * (1.0f + fabsf(vx) + fabsf(vy) + fabsf(vz));
+  const float tca = fmaf(vz, uz, fmaf(vy, uy, vx * ux));
+  const float wx = fmaf(-tca, ux, vx), wy = fmaf(-tca, uy, vy), wz = fmaf(-tca, uz, vz);   // v minus its part along the ray
+  const float d2 = fmaf(wz, wz, fmaf(wy, wy, wx * wx));
+  const float v2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  const float r2 = rs * rs;
+  return (v2 <= r2) | ((tca >= 0.0f) & (d2 <= r2) & (tca - rs <= tmax_u));
+}
+
+// nearest() through the hierarchy: identical result (same exact tests, same (t, orig) rule), the
+// spheres/boxes that cannot be hit or cannot beat the current best are skipped.
+__device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
+                                                int* k_out, double plane_thr) {
+  double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
+  for (int k = nS, e = nS + nP; k < e; ++k) {
+    double t = plane_t(P[k], o, d, plane_thr);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  const float ofx = (float)o.x, ofy = (float)o.y, ofz = (float)o.z;
+  float ux = (float)d.x, uy = (float)d.y, uz = (float)d.z;
+  const float len2 = fmaf(uz, uz, fmaf(uy, uy, ux * ux));
+  const float inv = 1.0f / sqrtf(len2), len = len2 * inv;        // directions need not be unit (rt_nearest_hit)
+  ux *= inv; uy *= inv; uz *= inv;
+  float tmax_u = best < 1e30 ? (float)best * len * 1.00001f + 1e-5f : 3.0e38f;
+  int i = 0;
+  while (i < ac.n_nodes) {
+    const BvhNode nd = ac.nodes[i];
+    if (!ray_may_touch(nd.cx, nd.cy, nd.cz, nd.r, ofx, ofy, ofz, ux, uy, uz, tmax_u)) { i = nd.skip; continue; }
+    for (int j = 0; j < nd.count; ++j) {
+      const int k = nd.first + j;
+      const float4 b = ac.pbound[k];
+      if (!ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u)) continue;
+      const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
+      const int og = P[k].orig;
+      if (t < best || (t == best && og < borig && bk >= 0)) {
+        best = t; bk = k; borig = og;
+        tmax_u = (float)best * len * 1.00001f + 1e-5f;
+      }
+    }
+    ++i;
+  }
+  *k_out = bk;
+  return best;
+}
+
 __device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
   if (p.type == 0) return sphere_normal(p, o, d, t);
   if (p.type == 1) return plane_normal(p, d);
@@ -205,12 +281,13 @@ __device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
 constexpr int SEQ_WALK_CAP = 1 << 16;
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
-                                              int* queries, bool seq = false, double plane_thr = HIT_EPS) {
+                                              int* queries, bool seq = false, double plane_thr = HIT_EPS,
+                                              const Accel* ac = nullptr) {
   double remaining = maxdist, trans = 1.0;
   const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
   for (int step = 0; step < cap; ++step) {
     if (seq && !(remaining > EPS)) break;                        // :303
-    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr);
+    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr, ac);
     ++*queries;
     if (!((t < remaining) && k >= 0)) break;                     // :269-272, :290-291
     trans *= mats[MAT_STRIDE * P[k].mat + 10];                   // :276-279

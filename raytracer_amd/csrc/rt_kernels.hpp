@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
       int k = -1; double t = RT_INF;
       if (active) {
         RayIn r = load_ray(level, slot, cam, fp.rs, q);
-        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr);
+        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &sc.ac);
         hit = k >= 0;
         if (level == 0) {
           // every pixel has exactly one level-0 ray: a plain store initialises the framebuffer
@@ -255,7 +255,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
       double dist = norm3(tl);
       d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
       d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr);
+      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, &sc.ac);
     } else {
       d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
       double ldist = norm3(tl);
@@ -283,7 +283,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
           double dist = norm3(ts);
           d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
           d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr);
+          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, &sc.ac);
         }
       T = total / (double)(n_sh * n_sh);                                           // :243
     }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_nearest_rays(DevScene sc, const doubl
   long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   d3 ro = mk3(o[3 * m], o[3 * m + 1], o[3 * m + 2]), rd = mk3(d[3 * m], d[3 * m + 1], d[3 * m + 2]);
-  int k; double t = nearest(sc.prims, sc.nS, sc.nP, sc.nB, ro, rd, &k);
+  int k; double t = nearest(sc.prims, sc.nS, sc.nP, sc.nB, ro, rd, &k, HIT_EPS, &sc.ac);
   d3 n = mk3(0, 0, 0);
   if (k >= 0) n = prim_normal(sc.prims[k], ro, rd, t);
   t_out[m] = t;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_rays(DevScene sc, const double
   if (m >= M) return;
   int q = 0;
   out[m] = shadow_walk(sc.prims, sc.nS, sc.nP, sc.nB, sc.mats, mk3(o[3 * m], o[3 * m + 1], o[3 * m + 2]),
-                       mk3(d[3 * m], d[3 * m + 1], d[3 * m + 2]), maxd[m], &q);
+                       mk3(d[3 * m], d[3 * m + 1], d[3 * m + 2]), maxd[m], &q, false, HIT_EPS, &sc.ac);
 }
 
 // rt_camera_rays: Camera.generate_rays_for_rows.

@@ -111,9 +111,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             tr[s] = (cellidx < n_cells) ? 1.0f : 0.0f;
             if (HAS_BOX) { ix[s] = raw_rcp(dx[s]); iy[s] = raw_rcp(dy[s]); iz[s] = raw_rcp(dz[s]); }
           }
-          int k = 0;
-          for (int e = sc.nS; k < e; ++k) {                   // spheres: sphere.py:49-71
-            const Prim& s_ = P[k];
+          // per-primitive blocks: everything that depends on (hit, primitive) once, then CH samples
+          auto do_sphere = [&](const Prim& s_) __attribute__((always_inline)) {   // sphere.py:49-71
             const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
             const float cc = (float)(((ocx * ocx + ocy * ocy) + ocz * ocz) - s_.a[4]);
             const f3 oc = mkf((float)ocx, (float)ocy, (float)ocz);
@@ -128,8 +127,26 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
               else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
             }
-          }
-          for (int e = sc.nS + sc.nP; k < e; ++k) {           // planes: infinite_plane.py:30-42
+          };
+          auto do_box = [&](const Prim& s_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
+            const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
+            const f3 hi = mkf((float)(s_.a[3] - p.x), (float)(s_.a[4] - p.y), (float)(s_.a[5] - p.z));
+            const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+              const float ax = lo.x * ix[HAS_BOX ? s : 0], bx = hi.x * ix[HAS_BOX ? s : 0];
+              const float ay = lo.y * iy[HAS_BOX ? s : 0], by = hi.y * iy[HAS_BOX ? s : 0];
+              const float az = lo.z * iz[HAS_BOX ? s : 0], bz = hi.z * iz[HAS_BOX ? s : 0];
+              const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+              const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+              const bool ok = tn <= tf;
+              const bool in1 = ok & (tn > T_LO) & (tn < md[s]);
+              const bool in2 = ok & (tf > T_LO) & (tf < md[s]);
+              if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
+              else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+            }
+          };
+          for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
             const Prim& s_ = P[k];
             const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
             const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
@@ -143,26 +160,41 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               else tr[s] *= in1 ? tau : 1.0f;
             }
           }
-          if (HAS_BOX) {
-            for (int e = sc.nS + sc.nP + sc.nB; k < e; ++k) { // boxes: cube.py:76-107 (slab roots)
-              const Prim& s_ = P[k];
-              const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
-              const f3 hi = mkf((float)(s_.a[3] - p.x), (float)(s_.a[4] - p.y), (float)(s_.a[5] - p.z));
-              const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
-#pragma unroll
-              for (int s = 0; s < CH; ++s) {
-                const float ax = lo.x * ix[s], bx = hi.x * ix[s];
-                const float ay = lo.y * iy[s], by = hi.y * iy[s];
-                const float az = lo.z * iz[s], bz = hi.z * iz[s];
-                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                const bool ok = tn <= tf;
-                const bool in1 = ok & (tn > T_LO) & (tn < md[s]);
-                const bool in2 = ok & (tf > T_LO) & (tf < md[s]);
-                if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
-                else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+          if (!LDS_SCENE && sc.ac.n_nodes > 0) {
+            // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
+            // to this light (all samples lie within RL of the light centre) and runs the sample block
+            // only for the spheres / boxes that can cross one of them.  Results are those of the
+            // brute-force loops below (the skipped primitives contribute a factor of exactly 1).
+            const float RL = n_sh > 1 ? 0.7072f * radius * 1.001f : 0.0f;
+            const float qa = dotf(tl, tl) - RL * RL, rqa = raw_rcp(qa);
+            const float pfx = (float)p.x, pfy = (float)p.y, pfz = (float)p.z;
+            const float e1 = fabsf(tl.x) + fabsf(tl.y) + fabsf(tl.z);
+            auto fan_may_touch = [&](float cx, float cy, float cz, float r) __attribute__((always_inline)) {
+              const float ux = pfx - cx, uy = pfy - cy, uz = pfz - cz;
+              const float rs = r + 4e-5f * (1.0f + e1 + fabsf(ux) + fabsf(uy) + fabsf(uz));
+              const float qb = fmaf(uz, tl.z, fmaf(uy, tl.y, ux * tl.x)) - rs * RL;
+              const float ta = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
+              const float xx = fmaf(ta, tl.x, ux), xy = fmaf(ta, tl.y, uy), xz = fmaf(ta, tl.z, uz);
+              const float w = fmaf(ta, RL, rs);
+              return (qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= w * w);
+            };
+            int i = 0;
+            while (i < sc.ac.n_nodes) {
+              const BvhNode nd = sc.ac.nodes[i];
+              if (!fan_may_touch(nd.cx, nd.cy, nd.cz, nd.r)) { i = nd.skip; continue; }
+              for (int j = 0; j < nd.count; ++j) {
+                const int k = nd.first + j;
+                const float4 b = sc.ac.pbound[k];
+                if (!fan_may_touch(b.x, b.y, b.z, b.w)) continue;
+                if (k < sc.nS) do_sphere(P[k]);
+                else if (HAS_BOX) do_box(P[k]);
               }
+              ++i;
             }
+          } else {
+            for (int k = 0; k < sc.nS; ++k) do_sphere(P[k]);
+            if (HAS_BOX)
+              for (int k = sc.nS + sc.nP, e = sc.n; k < e; ++k) do_box(P[k]);
           }
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];

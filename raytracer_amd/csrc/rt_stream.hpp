@@ -28,7 +28,7 @@ __global__ __launch_bounds__(BLOCK) void k_sa_trace(DevScene sc, DevCamera cam, 
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= M) return;
   const RayIn r = load_ray(ROOT ? 0 : 1, i, cam, fp.rs, q);
-  int k; const double t = nearest(sc.prims, sc.nS, sc.nP, sc.nB, r.o, r.d, &k);
+  int k; const double t = nearest(sc.prims, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, HIT_EPS, &sc.ac);
   HitRec h; h.slot = i; h.prim = k; h.t = t;
   rec[i] = h;
   flag[i] = k >= 0 ? 1u : 0u;
