@@ -87,41 +87,47 @@ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
   v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v;
 }
 
+struct BoxD { double lo[3], hi[3]; };
+
+BoxD prim_box(const Prim& p) {
+  BoxD b;
+  if (p.type == RT_SPHERE) { const double r = std::fabs(p.a[3]); for (int k = 0; k < 3; ++k) { b.lo[k] = p.a[k] - r; b.hi[k] = p.a[k] + r; } }
+  else for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(p.a[k], p.a[3 + k]); b.hi[k] = std::max(p.a[k], p.a[3 + k]); }
+  return b;
+}
+
 struct BvhBuilder {
   const std::vector<Prim>& prims;
   std::vector<BvhNode> nodes;
-  explicit BvhBuilder(const std::vector<Prim>& p) : prims(p) {}
-  // enclosing sphere of a set of spheres: centre of their common AABB, radius = max reach
-  static BoundD enclose(const std::vector<BoundD>& v) {
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (const BoundD& b : v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.c[k] - b.r); hi[k] = std::max(hi[k], b.c[k] + b.r); }
-    BoundD o; for (int k = 0; k < 3; ++k) o.c[k] = 0.5 * (lo[k] + hi[k]);
-    o.r = 0;
-    for (const BoundD& b : v) {
-      double d2 = 0; for (int k = 0; k < 3; ++k) d2 += (b.c[k] - o.c[k]) * (b.c[k] - o.c[k]);
-      o.r = std::max(o.r, std::sqrt(d2) + b.r);
-    }
-    return o;
+  int leaf = 8, fanout = 8;      // leaf <= 8 records (BvhNode::count has 4 bits)
+  explicit BvhBuilder(const std::vector<Prim>& p) : prims(p) {
+    if (const char* e = getenv("RT_BVH_LEAF")) leaf = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = getenv("RT_BVH_FANOUT")) fanout = std::min(64, std::max(2, atoi(e)));
   }
-  BoundD build(int first, int count) {
+  static void grow(BoxD* a, const BoxD& b) { for (int k = 0; k < 3; ++k) { a->lo[k] = std::min(a->lo[k], b.lo[k]); a->hi[k] = std::max(a->hi[k], b.hi[k]); } }
+  BoxD build(int first, int count) {
     const int idx = (int)nodes.size();
     nodes.push_back(BvhNode{});
-    BoundD bound;
-    if (count <= 8) {
-      std::vector<BoundD> v; for (int i = 0; i < count; ++i) v.push_back(prim_bound(prims[first + i]));
-      bound = enclose(v);
-      nodes[idx].first = first; nodes[idx].count = count;
+    BoxD box; for (int k = 0; k < 3; ++k) { box.lo[k] = 1e300; box.hi[k] = -1e300; }
+    int leaf_count = 0;
+    if (count <= leaf) {
+      for (int i = 0; i < count; ++i) grow(&box, prim_box(prims[first + i]));
+      leaf_count = count;
     } else {
-      long long child = 8; while (child * 8 < count) child *= 8;     // largest power of 8 below count
-      std::vector<BoundD> v;
-      for (long long off = 0; off < count; off += child) v.push_back(build(first + (int)off, (int)std::min<long long>(child, count - off)));
-      bound = enclose(v);
-      nodes[idx].first = first; nodes[idx].count = 0;
+      long long child = leaf; while (child * fanout < count) child *= fanout;   // leaf * fanout^k, the largest below count
+      for (long long off = 0; off < count; off += child) grow(&box, build(first + (int)off, (int)std::min<long long>(child, count - off)));
     }
-    const float4 f = to_float_bound(bound);
-    nodes[idx].cx = f.x; nodes[idx].cy = f.y; nodes[idx].cz = f.z; nodes[idx].r = f.w;
-    nodes[idx].skip = (int)nodes.size(); nodes[idx].pad = 0;
-    return bound;
+    for (int k = 0; k < 3; ++k) {                                      // round outward
+      float lo = (float)box.lo[k], hi = (float)box.hi[k];
+      if ((double)lo > box.lo[k]) lo = std::nextafter(lo, -INFINITY);
+      if ((double)hi < box.hi[k]) hi = std::nextafter(hi, INFINITY);
+      if (!(lo == lo)) lo = -3.0e38f;
+      if (!(hi == hi)) hi = 3.0e38f;
+      nodes[idx].lo[k] = std::max(lo, -3.0e38f); nodes[idx].hi[k] = std::min(hi, 3.0e38f);
+    }
+    nodes[idx].first = first;
+    nodes[idx].skip_count = ((uint32_t)leaf_count << 28) | (uint32_t)nodes.size();
+    return box;
   }
 };
 
@@ -135,7 +141,8 @@ void morton_sort(std::vector<Prim>& prims, int first, int count) {
     BoundD b = prim_bound(prims[first + i]);
     uint32_t code = 0;
     for (int k = 0; k < 3; ++k) {
-      double ext = hi[k] - lo[k];
+      // one scale for all axes: cells stay cubical in flat scenes (a segment then crosses few of them)
+      double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
       double u = ext > 0 ? (b.c[k] - lo[k]) / ext : 0.0;
       if (!(u >= 0)) u = 0;
       if (u > 1) u = 1;
@@ -239,7 +246,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   {
     const char* e = getenv("RT_ACCEL");
     const bool want = !(e && e[0] == '0');
-    if (want && (int)prims.size() > LDS_PRIMS && cnt[0] + cnt[2] > 0) {
+    if (want && (int)prims.size() > LDS_PRIMS && cnt[0] + cnt[2] > 0 && prims.size() < (1u << 27)) {
       morton_sort(prims, 0, cnt[0]);
       morton_sort(prims, cnt[0] + cnt[1], cnt[2]);
       BvhBuilder bb(prims);

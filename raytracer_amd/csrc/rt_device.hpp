@@ -31,16 +31,18 @@ static_assert(sizeof(Prim) == 64, "Prim must be 64 bytes");
 
 // Conservative culling hierarchy for scenes too large for the brute-force loops (host-built in
 // rt_api.hip).  It never changes a result: a node / primitive is skipped only when
-// its bounding sphere (inflated for fp32 rounding) cannot be touched by the query, and every
+// its bound (a box for nodes, a sphere per record; inflated for fp32 rounding) cannot be touched by the query, and every
 // surviving primitive goes through the same exact test as in the brute-force loop; ties are still
 // broken by (t, orig).  Nodes are stored in depth-first order with skip links, so a lane walks the
 // tree without a stack: hit -> next node, miss -> node.skip.  Leaves own <= 8 consecutive records
 // of ONE type (spheres and boxes are Morton-sorted inside their type range); planes are unbounded
 // and stay outside the tree (always tested).
 struct __attribute__((aligned(16))) BvhNode {
-  float cx, cy, cz, r;     // bounding sphere
-  int32_t first, count;    // leaf: records [first, first+count); inner node: count == 0
-  int32_t skip, pad;       // index of the next node when this one is missed
+  float lo[3], hi[3];      // axis-aligned bounds (rounded outward on the host)
+  int32_t first;           // leaf: records [first, first+count); inner node: count == 0
+  uint32_t skip_count;     // low 28 bits: index of the next node when this one is missed; high 4: count
+  __host__ __device__ int count() const { return (int)(skip_count >> 28); }
+  __host__ __device__ int skip() const { return (int)(skip_count & 0x0FFFFFFFu); }
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 struct Accel {
@@ -216,6 +218,43 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
   return best;
 }
 
+// Stackless walk of the hierarchy by one lane.  node_hit(node) / prim_may(bound) are the
+// conservative tests of the query, on_prim(k) runs the exact code for record k.  The walk is
+// latency-bound (every step depends on a load), so the successor of a hit node is fetched
+// speculatively while the node is being tested and the <= 8 record bounds of a leaf are fetched
+// together before any of them is tested.
+template <class NodeHit, class PrimMay, class OnPrim>
+__device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, PrimMay prim_may, OnPrim on_prim) {
+  const int n = ac.n_nodes;
+  if (n <= 0) return;
+  int i = 0;
+  BvhNode nd = ac.nodes[0];
+  while (i < n) {
+    const int nxt = i + 1;
+    const BvhNode nx = ac.nodes[nxt < n ? nxt : i];
+    if (node_hit(nd)) {
+      const int nj = nd.count();
+      if (nj > 0) {
+        float4 b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = ac.pbound[nd.first + (j < nj ? j : 0)];
+        uint32_t cand = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cand |= (j < nj && prim_may(b[j])) ? (1u << j) : 0u;
+        while (cand) {
+          const int j = __ffs((int)cand) - 1;
+          cand &= cand - 1;
+          on_prim(nd.first + j);
+        }
+      }
+      i = nxt; nd = nx;
+    } else {
+      i = nd.skip();
+      if (i < n) nd = ac.nodes[i];
+    }
+  }
+}
+
 // Does the ray (origin of, UNIT direction uf, fp32 copies) possibly touch the sphere (c, r) at a
 // parameter <= tmax_u (unit-length parameter, already rounded up)?  Conservative: the slack covers
 // the fp32 rounding of the ray, of the bound and of this arithmetic by two orders of magnitude.
@@ -247,23 +286,28 @@ __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int 
   const float inv = 1.0f / sqrtf(len2), len = len2 * inv;        // directions need not be unit (rt_nearest_hit)
   ux *= inv; uy *= inv; uz *= inv;
   float tmax_u = best < 1e30 ? (float)best * len * 1.00001f + 1e-5f : 3.0e38f;
-  int i = 0;
-  while (i < ac.n_nodes) {
-    const BvhNode nd = ac.nodes[i];
-    if (!ray_may_touch(nd.cx, nd.cy, nd.cz, nd.r, ofx, ofy, ofz, ux, uy, uz, tmax_u)) { i = nd.skip; continue; }
-    for (int j = 0; j < nd.count; ++j) {
-      const int k = nd.first + j;
-      const float4 b = ac.pbound[k];
-      if (!ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u)) continue;
+  // slab test of the node boxes: inflating a box by dl in space covers an error of dl*|1/u| in t
+  const float ix = fabsf(ux) > 1e-20f ? 1.0f / ux : 1e30f, iy = fabsf(uy) > 1e-20f ? 1.0f / uy : 1e30f,
+              iz = fabsf(uz) > 1e-20f ? 1.0f / uz : 1e30f;
+  const float dl = 4e-5f * (1.0f + fabsf(ofx) + fabsf(ofy) + fabsf(ofz));
+  bvh_walk(ac,
+    [&](const BvhNode& nd) __attribute__((always_inline)) {
+      const float ax = (nd.lo[0] - dl - ofx) * ix, bx = (nd.hi[0] + dl - ofx) * ix;
+      const float ay = (nd.lo[1] - dl - ofy) * iy, by = (nd.hi[1] + dl - ofy) * iy;
+      const float az = (nd.lo[2] - dl - ofz) * iz, bz = (nd.hi[2] + dl - ofz) * iz;
+      const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+      const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_u));
+      return tn <= tf * 1.00001f + 1e-5f;
+    },
+    [&](const float4& b) __attribute__((always_inline)) { return ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u); },
+    [&](int k) __attribute__((always_inline)) {
       const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
       const int og = P[k].orig;
       if (t < best || (t == best && og < borig && bk >= 0)) {
         best = t; bk = k; borig = og;
         tmax_u = (float)best * len * 1.00001f + 1e-5f;
       }
-    }
-    ++i;
-  }
+    });
   *k_out = bk;
   return best;
 }

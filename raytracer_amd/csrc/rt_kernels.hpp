@@ -68,6 +68,23 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
   return lds;
 }
 
+// Small hierarchies (<= LDS_NODES nodes, 32 KiB) are staged in LDS too: the walk is a chain of
+// dependent loads, LDS latency is several times shorter than L2's.
+constexpr int LDS_NODES = 1024;
+template <bool LDS_SCENE>
+__device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
+  Accel a = sc.ac;
+  if (LDS_SCENE) { a.n_nodes = 0; return a; }
+  if (a.n_nodes <= 0 || a.n_nodes > LDS_NODES) return a;
+  const int words = a.n_nodes * (int)(sizeof(BvhNode) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(a.nodes);
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  a.nodes = lds;
+  return a;
+}
+
 // Wave-level dynamic work grab: returns the base index of a 64-item chunk (all lanes get it).
 __device__ __forceinline__ uint32_t grab64(uint32_t* cursor) {
   uint32_t base = 0;
@@ -126,9 +143,11 @@ template <typename FB, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                  HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
   __shared__ HitRec s_hits[TRACE_CHUNK];
   __shared__ uint32_t s_count, s_base;
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   uint32_t count = C->n_rays[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t n_chunks = (count + TRACE_CHUNK - 1) / TRACE_CHUNK;
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
       int k = -1; double t = RT_INF;
       if (active) {
         RayIn r = load_ray(level, slot, cam, fp.rs, q);
-        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &sc.ac);
+        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &ac);
         hit = k >= 0;
         if (level == 0) {
           // every pixel has exactly one level-0 ray: a plain store initialises the framebuffer
@@ -234,7 +253,7 @@ struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading resu
 template <typename JIT>
 __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Prim* __restrict__ P, const RayIn& r,
                                                     const HitRec& hr, int n_sh, JIT& jit, int* queries,
-                                                    bool seq = false, double pthr = HIT_EPS) {
+                                                    bool seq = false, double pthr = HIT_EPS, const Accel* ac = nullptr) {
   ExactHit out;
   const Prim& pr = P[hr.prim];
   const double t = hr.t;
@@ -255,7 +274,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
       double dist = norm3(tl);
       d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
       d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, &sc.ac);
+      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac);
     } else {
       d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
       double ldist = norm3(tl);
@@ -283,7 +302,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
           double dist = norm3(ts);
           d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
           d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, &sc.ac);
+          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac);
         }
       T = total / (double)(n_sh * n_sh);                                           // :243
     }
@@ -327,7 +346,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
                                                        RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                        FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t lane = __lane_id();
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
       r = load_ray(level, hr.slot, cam, fp.rs, q);
       JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = global_pixel(fp.rs, r.lp); jit.depth = (uint32_t)level;
       int queries = 0;
-      ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries, fp.sequential != 0, fp.plane_thr);
+      ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries, fp.sequential != 0, fp.plane_thr, &ac);
       hp = e.hp; n = e.n; mat = e.mat;
       if (seq_background_term(fp, level, mat)) {                                          // :370-377
         e.c[0] += sc.bg[0] * mat[10]; e.c[1] += sc.bg[1] * mat[10]; e.c[2] += sc.bg[2] * mat[10];

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                       float* __restrict__ fb, int n_chunks) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t lane = __lane_id();
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               else tr[s] *= in1 ? tau : 1.0f;
             }
           }
-          if (!LDS_SCENE && sc.ac.n_nodes > 0) {
+          if (!LDS_SCENE && ac.n_nodes > 0) {
             // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
             // to this light (all samples lie within RL of the light centre) and runs the sample block
             // only for the spheres / boxes that can cross one of them.  Results are those of the
@@ -178,19 +180,24 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               const float w = fmaf(ta, RL, rs);
               return (qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= w * w);
             };
-            int i = 0;
-            while (i < sc.ac.n_nodes) {
-              const BvhNode nd = sc.ac.nodes[i];
-              if (!fan_may_touch(nd.cx, nd.cy, nd.cz, nd.r)) { i = nd.skip; continue; }
-              for (int j = 0; j < nd.count; ++j) {
-                const int k = nd.first + j;
-                const float4 b = sc.ac.pbound[k];
-                if (!fan_may_touch(b.x, b.y, b.z, b.w)) continue;
+            // node boxes: segment p -> Lp against the box grown by RL (+ fp32 slack), 0 <= tau <= 1
+            const float gx = fabsf(tl.x) > 1e-20f ? raw_rcp(tl.x) : 1e30f, gy = fabsf(tl.y) > 1e-20f ? raw_rcp(tl.y) : 1e30f,
+                        gz = fabsf(tl.z) > 1e-20f ? raw_rcp(tl.z) : 1e30f;
+            const float grow = RL + 4e-5f * (1.0f + e1 + fabsf(pfx) + fabsf(pfy) + fabsf(pfz));
+            bvh_walk(ac,
+              [&](const BvhNode& nd) __attribute__((always_inline)) {
+                const float ax = (nd.lo[0] - grow - pfx) * gx, bx = (nd.hi[0] + grow - pfx) * gx;
+                const float ay = (nd.lo[1] - grow - pfy) * gy, by = (nd.hi[1] + grow - pfy) * gy;
+                const float az = (nd.lo[2] - grow - pfz) * gz, bz = (nd.hi[2] + grow - pfz) * gz;
+                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), 1.0f));
+                return tn <= tf + 1e-5f;
+              },
+              [&](const float4& b) __attribute__((always_inline)) { return fan_may_touch(b.x, b.y, b.z, b.w); },
+              [&](int k) __attribute__((always_inline)) {
                 if (k < sc.nS) do_sphere(P[k]);
                 else if (HAS_BOX) do_box(P[k]);
-              }
-              ++i;
-            }
+              });
           } else {
             for (int k = 0; k < sc.nS; ++k) do_sphere(P[k]);
             if (HAS_BOX)

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void k_sa_shade(DevScene sc, DevCamera cam, 
   const RayIn r = load_ray(ROOT ? 0 : 1, hr.slot, cam, fp.rs, q);
   JitTable jit; jit.tab = table; jit.H = H; jit.h = h; jit.n_cells = n_cells;
   int queries = 0;
-  const ExactHit e = shade_hit_exact(sc, sc.prims, r, hr, fp.n_shadow, jit, &queries);
+  const ExactHit e = shade_hit_exact(sc, sc.prims, r, hr, fp.n_shadow, jit, &queries, false, HIT_EPS, &sc.ac);
   double* dst = fb + 3 * (size_t)r.lp;
   dst[0] += r.w.x * e.c[0]; dst[1] += r.w.y * e.c[1]; dst[2] += r.w.z * e.c[2];           // :563
   atomicAdd(queries_out, (unsigned long long)queries);
