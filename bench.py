@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--block-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with a full-frame render on rank 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,16 +130,40 @@ def main():
 
     tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
     dtype = torch.float32 if precision == "fp32" else torch.float64
-    tile = torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev)
+    # N > 1: frames are pipelined two deep — the gather of frame k (comm stream) overlaps the render of
+    # frame k+1 (render stream, into the other tile buffer).  RT_BENCH_PIPELINE=0 serialises them.
+    pipelined = world > 1 and os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
+    n_buf = 2 if pipelined else 1
+    tiles = [torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev) for _ in range(n_buf)]
+    tile = tiles[0]
     frame = torch.empty((H, W, 3), dtype=dtype, device=dev) if (world > 1 and rank == 0) else None
     scratch = new_scratch(tile, world) if (world > 1 and rank == 0) else None
     flags = _lib.RT_FLAG_ASYNC | (0 if args.no_timing else _lib.RT_FLAG_TIMING)
+    if pipelined:
+        render_stream, comm_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        gs.set_stream(render_stream.cuda_stream)
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        tile_free = [None, None]
+    frame_no = [0]
 
     def step(stats):
+        k = frame_no[0]; frame_no[0] += 1
+        if not pipelined:
+            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                      part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
+            if world > 1:
+                gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+            return
+        b = k & 1
+        if tile_free[b] is not None:
+            render_stream.wait_event(tile_free[b])          # the gather of frame k-2 has read this tile
         gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
-                  part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
-        if world > 1:
-            gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+                  part=rank, n_parts=world, out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
+        rendered[b].record(render_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(rendered[b])
+            gather_tiles(tiles[b], tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+            ev = torch.cuda.Event(); ev.record(comm_stream); tile_free[b] = ev
 
     def barrier():
         if world > 1:
@@ -166,6 +191,13 @@ def main():
         elapsed = float(tmax[0]); rays, hits, shadow = (float(x) for x in sums)
     else:
         rays, hits, shadow = float(last.rays), float(last.hits), float(last.shadow_rays)
+
+    verify = None
+    if args.verify and world > 1 and rank == 0:
+        full = torch.empty((H, W, 3), dtype=dtype, device=dev)
+        gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=full.data_ptr())
+        torch.cuda.synchronize()
+        verify = {"max_abs_diff_vs_single_gpu_frame": float((full - frame).abs().max())}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -204,9 +236,14 @@ def main():
             "data": "reference scene values (scenes/pool.txt etc. in-repo), pixel-keyed jitter seed 1234",
             "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
                        "shadow_rays": int(shadow), "row_blocks": args.block_rows,
-                       "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")},
+                       "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")
+                                      + (", frames pipelined 2 deep (gather k overlaps render k+1)" if pipelined else "")},
             "roofline": roofline,
         }
+        if world > 1:
+            roofline["traffic"] = None      # the PMC pass (profiles/) measured full-frame launches on one GPU
+        if verify is not None:
+            out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(args.workload, gs, cam, st, mats, surfs, lights, W, H, precision)
             out["cpu_baseline"] = base
