@@ -46,6 +46,7 @@ struct FrameParams {
   int32_t n_shadow, max_depth;
   uint32_t seed;
   uint32_t queue_cap;
+  uint32_t debug;        // RT_DEBUG_STATS=1: kernels count events into Counters::queries (fp32 mode)
   uint32_t sequential;   // RT_FLAG_SEQUENTIAL: semantics of the reference's per-pixel render()
   double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
 };

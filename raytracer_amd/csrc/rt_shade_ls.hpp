@@ -166,8 +166,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   constexpr int MAXN = MAXS + MAXP + MAXB;
   __shared__ Prim s_prims[MAXN];
   __shared__ float2 s_cells[LS_MAX_CELLS];
-  __shared__ double s_lightd[LS_MAX_LIGHTS][LIGHT_STRIDE];   // as uploaded (position needs fp64)
+  __shared__ float s_lightf[LS_MAX_LIGHTS][LIGHT_STRIDE];    // lights as fp32 (the shadow origin's epsilon lives in cc / num)
+  __shared__ float4 s_sphf[MAXS];                             // sphere centres + radii as fp32
   __shared__ double s_matd[LS_MAX_MATS][MAT_STRIDE];
+  // exact fp64 geometry of each lane's hit, parked for the spawn step (hit point, normal, ray direction,
+  // weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
+  __shared__ double s_geo[12][BLOCK];
   __shared__ uint32_t s_wcnt[BLOCK / 64][2];
   __shared__ uint32_t s_base;
   const int n_sh = fp.n_shadow;
@@ -178,7 +182,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
     uint4* dst = reinterpret_cast<uint4*>(s_prims);
     for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
-    for (int i = threadIdx.x; i < sc.nL * LIGHT_STRIDE; i += BLOCK) (&s_lightd[0][0])[i] = sc.lights[i];
+    for (int i = threadIdx.x; i < sc.nL * LIGHT_STRIDE; i += BLOCK) (&s_lightf[0][0])[i] = (float)sc.lights[i];
+    for (int i = threadIdx.x; i < MAXS; i += BLOCK) {
+      s_sphf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (i < sc.nS) s_sphf[i] = make_float4((float)sc.prims[i].a[0], (float)sc.prims[i].a[1], (float)sc.prims[i].a[2], (float)sc.prims[i].a[3]);
+    }
     for (int i = threadIdx.x; i < sc.nM * MAT_STRIDE; i += BLOCK) (&s_matd[0][0])[i] = sc.mats[i];
     // per-light table of cell base offsets: -radius/2 + cell*(i or j)   (ray_tracer.py:215, 224-225)
     for (int e = threadIdx.x; e < sc.nL * n_cells; e += BLOCK) {
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     const LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_cc, a_A, a_B, a_C, a_sgn, a_tauS, a_num, a_D0, a_D1, a_D2, a_tauP,
                                                a_blo, a_bhi, a_tauB, a_binside};
     d3 p = mk3(0, 0, 0);
+    f3 pf = mkf(0, 0, 0);
     f3 nf = mkf(0, 0, 1), v = mkf(0, 0, 1), wgt = mkf(0, 0, 0);
     int mat_idx = 0, own = -1;
     bool own_is_plane = false;
@@ -226,6 +235,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       mat_idx = op.mat; own = hr.prim; own_is_plane = op.type == 1;
       lp = r.lp; gpix = global_pixel(fp.rs, lp);
       wgt = tof(r.w);
+      pf = tof(p);
+      if (spawn_level) {
+        const uint32_t t_ = threadIdx.x;
+        s_geo[0][t_] = hp.x; s_geo[1][t_] = hp.y; s_geo[2][t_] = hp.z;
+        s_geo[3][t_] = n.x; s_geo[4][t_] = n.y; s_geo[5][t_] = n.z;
+        s_geo[6][t_] = r.d.x; s_geo[7][t_] = r.d.y; s_geo[8][t_] = r.d.z;
+        s_geo[9][t_] = r.w.x; s_geo[10][t_] = r.w.y; s_geo[11][t_] = r.w.z;
+      }
     }
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
@@ -267,8 +284,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
     for (int li = 0; li < sc.nL; ++li) {
-      const double* lg = s_lightd[li];
-      const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
+      const float* lg = s_lightf[li];
+      const f3 tl = mkf(lg[0] - pf.x, lg[1] - pf.y, lg[2] - pf.z);
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
@@ -276,15 +293,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const f3 right = normalize_clamped(crossf(ld, ref));
       const f3 up = normalize_clamped(crossf(right, ld));
       const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
-      const float radius = (float)lg[8];
+      const float radius = lg[8];
       const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
       const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
 #pragma unroll
       for (int k = 0; k < MAXS; ++k) {
         a_A[k] = a_B[k] = a_C[k] = 0.0f;
         if (k < nS) {
-          const Prim& s_ = P[k];
-          const f3 oc = mkf((float)(p.x - s_.a[0]), (float)(p.y - s_.a[1]), (float)(p.z - s_.a[2]));
+          const float4 sf = s_sphf[k];
+          const f3 oc = mkf(pf.x - sf.x, pf.y - sf.y, pf.z - sf.z);
           a_A[k] = dotf(oc, tl); a_B[k] = dotf(oc, right); a_C[k] = dotf(oc, up);
         }
       }
@@ -305,58 +322,85 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       // Every sample lies within RL of the light centre, so the segment p -> sample stays within RL
       // of the segment p -> Lp.
       uint32_t act = 0;
+      bool lane_can = false;     // some primitive may cross some shadow segment of this lane
+      bool lane_full = false;    // opaque scenes: one sphere certainly blocks EVERY sample of this lane
       {
         // Sphere k can cross the segment p -> S of some sample S only if, for some tau in [0,1],
         // |oc + tau*tl| <= r + tau*RL (the segments to all samples fan out inside a cone around
         // p -> Lp):  g(tau) = tau^2 (T0 - RL^2) + 2 tau (A - r RL) + cc <= 0, minimised on [0,1].
         const float RL = 0.7072f * radius * 1.001f;
         const float qa = T0 - RL * RL, rqa = raw_rcp(qa);
+        const float rT0 = rl * rl;                                             // 1 / |tl|^2
+        const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
           if (k < nS) {
-            const float r = (float)P[k].a[3];
+            const float r = s_sphf[k].w;
             const float qb = a_A[k] - r * RL;
             const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
             const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), a_cc[k]);
-            const bool can = (qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(a_cc[k]) + r * r));
+            // origin outside the sphere and every sample direction leaves it (oc.ts > 0 for all samples):
+            // both roots are <= 0 — the lit side of the hit's own sphere, spheres behind the hit
+            const float bt_lo = a_A[k] - hw * (fabsf(a_B[k]) + fabsf(a_C[k]));
+            const bool away = (a_cc[k] >= 0.0f) & (bt_lo > 1e-5f * (fabsf(a_A[k]) + 1e-3f));
+            const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(a_cc[k]) + r * r))) & !away;
+            lane_can |= can;
             if (__any(active & can)) act |= 1u << k;
+            if (OPAQUE) {
+              // Umbra: at the parameter ts of closest approach of the central segment, the whole fan
+              // cross-section (radius ts*RL around p + ts*tl) lies inside the sphere while p is outside
+              // it -> every segment p -> S enters the sphere at a parameter in (0, ts), ts < 1.
+              const float ts = fminf(fmaxf(-a_A[k] * rT0, 0.0f), 1.0f);
+              const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * a_A[k]), a_cc[k] + r * r);     // |oc + ts*tl|^2
+              const float room = r * 0.999f - ts * RL;
+              lane_full |= (a_cc[k] > 0.0f) & (room > 0.0f) & (dist2 < room * room);
+            }
           }
         }
-        const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
           if (k < nP) {
             const float spread = hw * (fabsf(a_D1[k]) + fabsf(a_D2[k])) + 1e-6f * fabsf(a_D0[k]);
             // tau = num / den in (0, 1) needs num and den of the same sign
             const bool can = a_num[k] < 0.0f ? (a_D0[k] - spread <= 0.0f) : (a_num[k] > 0.0f ? (a_D0[k] + spread >= 0.0f) : true);
+            lane_can |= can;
             if (__any(active & can)) act |= 0x10000u << k;
           }
         }
+        if (MAXB > 0) lane_can |= nB > 0;
       }
       const float2* cells = s_cells + li * n_cells;
       float total;
-      if (__any(need_lo))
+      if (!__any(active & lane_can & !lane_full)) {
+        // No lane of the wave has a penumbra candidate for this light: every lane is either fully lit
+        // (all n^2 terms are exactly 1) or in the umbra of one opaque sphere (all terms exactly 0).
+        total = lane_full ? 0.0f : (float)n_cells;
+        if (fp.debug && lane == 0) atomicAdd(&C->queries, 1ull);
+      } else if (__any(need_lo))
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                    T0, T1, T2);
       else
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                     T0, T1, T2);
+      if (fp.debug && lane == 0) atomicAdd(&C->queries, 1ull << 32);
       const float T = total * inv_cells;
-      const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                         // ray_tracer.py:543
+      const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
       const float ndl = fmaxf(nt * rl, 0.0f);
       const float s1 = I * ndl;
-      dif0 = fmaf(kd0 * (float)lg[3], s1, dif0);
-      dif1 = fmaf(kd1 * (float)lg[4], s1, dif1);
-      dif2 = fmaf(kd2 * (float)lg[5], s1, dif2);
+      dif0 = fmaf(kd0 * lg[3], s1, dif0);
+      dif1 = fmaf(kd1 * lg[4], s1, dif1);
+      dif2 = fmaf(kd2 * lg[5], s1, dif2);
       const float dn = -nt * rl;                                                          // (-l).n
       const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -ld.x), fmaf(-2.0f * dn, nf.y, -ld.y), fmaf(-2.0f * dn, nf.z, -ld.z));
       const float rdv = fmaxf(dotf(rf, v), 0.0f);
-      const float pw = (shin == 0.0f) ? 1.0f : (rdv > 0.0f ? powf(rdv, shin) : 0.0f);     // np.power(0, 0) == 1
-      const float s2 = I * pw * (float)lg[6];
-      spc0 = fmaf(ks0 * (float)lg[3], s2, spc0);
-      spc1 = fmaf(ks1 * (float)lg[4], s2, spc1);
-      spc2 = fmaf(ks2 * (float)lg[5], s2, spc2);
+      // rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals
+      // (v_log_f32 / v_exp_f32, 1 ulp each; log2(0) = -inf -> 0); np.power(0, 0) == 1
+      const float pw = (shin == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
+      const float s2 = I * pw * lg[6];
+      spc0 = fmaf(ks0 * lg[3], s2, spc0);
+      spc1 = fmaf(ks1 * lg[4], s2, spc1);
+      spc2 = fmaf(ks2 * lg[5], s2, spc2);
     }
     (void)own;
 
@@ -391,11 +435,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const uint32_t preR = __builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
       const uint32_t sT = base + preT, sR = base + (uint32_t)__popcll(mT) + preR;
       if (needT || needR) {
-        // recompute the fp64 hit geometry (cheaper than keeping ~30 VGPRs live through phase 2)
-        const HitRec hr = hits[h];
-        const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
-        const d3 n = prim_normal(P[hr.prim], r.o, r.d, hr.t);
-        const d3 hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
+        const uint32_t t_ = threadIdx.x;
+        const d3 hp = mk3(s_geo[0][t_], s_geo[1][t_], s_geo[2][t_]);
+        const d3 n = mk3(s_geo[3][t_], s_geo[4][t_], s_geo[5][t_]);
+        RayIn r; r.d = mk3(s_geo[6][t_], s_geo[7][t_], s_geo[8][t_]); r.w = mk3(s_geo[9][t_], s_geo[10][t_], s_geo[11][t_]);
+        r.lp = lp;
         if (needT) {
           if (sT < fp.queue_cap) {
             nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;

@@ -28,9 +28,15 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--scale", type=int, default=1, help="divide width/height by this")
     ap.add_argument("--check", action="store_true", help="compare a 1/4-size frame with the oracle")
+    ap.add_argument("--n-shadow", type=int, default=None, help="override the shadow-ray root (cost breakdowns)")
+    ap.add_argument("--depth", type=int, default=None, help="override the recursion cap")
     args = ap.parse_args()
     cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
     W //= args.scale; H //= args.scale
+    if args.n_shadow is not None:
+        st.root_number_shadow_rays = args.n_shadow
+    if args.depth is not None:
+        st.max_recursions = args.depth
     n_shadow, max_depth = st.root_number_shadow_rays, st.max_recursions
     cam.setup(W / H)
     packed = pack_scene(mats, surfs, lights, st.background_color)
