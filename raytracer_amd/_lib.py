@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIBRARY") or os.path.join(_HERE, "librt_hip.so")   # RT_HIP_LIBRARY: e.g. the audit build
 
 RT_OK = 0
 RT_ERR_QUEUE_OVERFLOW = -4

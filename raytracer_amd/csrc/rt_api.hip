@@ -369,6 +369,12 @@ static int drain(rt_scene* s) {
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))
       fprintf(stderr, "[rt debug] k_shade_ls (wave, light) pairs: %llu total, %llu without a sample loop\n",
               (unsigned long long)(c.queries >> 32), (unsigned long long)(c.queries & 0xFFFFFFFFull));
+    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & 2))
+      fprintf(stderr, "[rt debug] shortcut audit: fully-lit claims wrong %llu, umbra claims wrong %llu, penumbra lanes %llu of %llu\n",
+              (unsigned long long)c.dbg[0], (unsigned long long)c.dbg[1], (unsigned long long)c.dbg[2], (unsigned long long)c.dbg[3]);
+    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && c.dbg[0])
+      fprintf(stderr, "[rt debug] k_shade_fast hierarchy walks: %llu; per walk: %.1f nodes tested (bounds of hit leaves incl.: %.1f record bounds), %.2f records processed\n",
+              (unsigned long long)c.dbg[0], (double)c.dbg[1] / c.dbg[0], (double)c.dbg[2] / c.dbg[0], (double)c.dbg[3] / c.dbg[0]);
     if (pf.user) {
       rt_stats st; std::memset(&st, 0, sizeof st);
       st.levels = pf.levels;
@@ -711,7 +717,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
   fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
   fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)s->cap_queue;
-  fp.debug = getenv("RT_DEBUG_STATS") ? 1u : 0u;
+  fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
   fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
   fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
   DevCamera cam = to_dev_camera(camera);

@@ -15,6 +15,14 @@
 
 namespace rt {
 
+// Audit / statistics code in the kernels exists only in the debug build (make debug ->
+// librt_hip_debug.so, selected with RT_HIP_LIBRARY); in the product library RT_DBG() is a constant 0.
+#ifdef RT_DEBUG_KERNEL
+#define RT_DBG(fp) ((fp).debug)
+#else
+#define RT_DBG(fp) 0u
+#endif
+
 constexpr int MAX_LEVELS = 32;
 constexpr int BLOCK = 256;
 constexpr int LDS_PRIMS = 128;   // scenes up to this many primitives are staged in LDS (8 KiB)
@@ -27,6 +35,7 @@ struct Counters {
   unsigned long long queries;   // shadow-walk nearest-hit queries (fp64 kernels)
   uint32_t overflow;
   uint32_t pad;
+  unsigned long long dbg[4];    // RT_DEBUG_STATS=1: kernel-specific event counts
 };
 
 // Radiance-ray queue of one level, struct-of-arrays so that a wave's loads/stores coalesce.

@@ -184,8 +184,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             const float gx = fabsf(tl.x) > 1e-20f ? raw_rcp(tl.x) : 1e30f, gy = fabsf(tl.y) > 1e-20f ? raw_rcp(tl.y) : 1e30f,
                         gz = fabsf(tl.z) > 1e-20f ? raw_rcp(tl.z) : 1e30f;
             const float grow = RL + 4e-5f * (1.0f + e1 + fabsf(pfx) + fabsf(pfy) + fabsf(pfz));
+            unsigned dbg_nodes = 0, dbg_bounds = 0, dbg_cands = 0;
             bvh_walk(ac,
               [&](const BvhNode& nd) __attribute__((always_inline)) {
+                if (RT_DBG(fp)) { ++dbg_nodes; dbg_bounds += nd.count(); }
                 const float ax = (nd.lo[0] - grow - pfx) * gx, bx = (nd.hi[0] + grow - pfx) * gx;
                 const float ay = (nd.lo[1] - grow - pfy) * gy, by = (nd.hi[1] + grow - pfy) * gy;
                 const float az = (nd.lo[2] - grow - pfz) * gz, bz = (nd.hi[2] + grow - pfz) * gz;
@@ -195,9 +197,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               },
               [&](const float4& b) __attribute__((always_inline)) { return fan_may_touch(b.x, b.y, b.z, b.w); },
               [&](int k) __attribute__((always_inline)) {
+                if (RT_DBG(fp)) ++dbg_cands;
                 if (k < sc.nS) do_sphere(P[k]);
                 else if (HAS_BOX) do_box(P[k]);
               });
+            if (RT_DBG(fp)) {
+              atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], (unsigned long long)dbg_nodes);
+              atomicAdd(&C->dbg[2], (unsigned long long)dbg_bounds); atomicAdd(&C->dbg[3], (unsigned long long)dbg_cands);
+            }
           } else {
             for (int k = 0; k < sc.nS; ++k) do_sphere(P[k]);
             if (HAS_BOX)

@@ -200,6 +200,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   }
   const Prim* P = s_prims;
   const int nS = sc.nS, nP = sc.nP, nB = sc.nB;
+  float umbra_t0_max = 3.0e38f;                              // 1000 * (smallest sphere radius)^2
+  for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t n_iters = (count + BLOCK - 1) / BLOCK;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         s_geo[9][t_] = r.w.x; s_geo[10][t_] = r.w.y; s_geo[11][t_] = r.w.z;
       }
     }
+    bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
       a_cc[k] = 1.0f; a_sgn[k] = -1.0f;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         const double ox = p.x - s_.a[0], oy = p.y - s_.a[1], oz = p.z - s_.a[2];
         a_cc[k] = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
         a_sgn[k] = a_cc[k] < 0.0f ? 1.0f : -1.0f;
+        near_scene &= fabsf(a_cc[k]) < 1000.0f * (float)s_.a[4];
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -352,11 +356,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
               // it -> every segment p -> S enters the sphere at a parameter in (0, ts), ts < 1.
               const float ts = fminf(fmaxf(-a_A[k] * rT0, 0.0f), 1.0f);
               const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * a_A[k]), a_cc[k] + r * r);     // |oc + ts*tl|^2
+              // fp32 cancellation bound of dist2 (hits far from the scene: |oc|^2 ~ T0 >> r^2 -> no claim)
               const float room = r * 0.999f - ts * RL;
               lane_full |= (a_cc[k] > 0.0f) & (room > 0.0f) & (dist2 < room * room);
             }
           }
         }
+        // dist2 above is a difference of terms as large as T0 and |oc|^2: its fp32 cancellation error
+        // ~4e-7 (|cc| + r^2 + T0) stays below the 0.2 % margin of `room` only for hits near the scene
+        lane_full &= near_scene & (T0 < umbra_t0_max);
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
           if (k < nP) {
@@ -371,18 +379,25 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       }
       const float2* cells = s_cells + li * n_cells;
       float total;
-      if (!__any(active & lane_can & !lane_full)) {
+      if (RT_DBG(fp) & 8u) act = 0xFFFFFFFFu;
+      if (!(RT_DBG(fp) & 2u) && !__any(active & lane_can & !lane_full)) {
         // No lane of the wave has a penumbra candidate for this light: every lane is either fully lit
         // (all n^2 terms are exactly 1) or in the umbra of one opaque sphere (all terms exactly 0).
         total = lane_full ? 0.0f : (float)n_cells;
-        if (fp.debug && lane == 0) atomicAdd(&C->queries, 1ull);
-      } else if (__any(need_lo))
+        if (RT_DBG(fp) && lane == 0) atomicAdd(&C->queries, 1ull);
+      } else if ((RT_DBG(fp) & 4u) || __any(need_lo))
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                    T0, T1, T2);
       else
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                     T0, T1, T2);
-      if (fp.debug && lane == 0) atomicAdd(&C->queries, 1ull << 32);
+      if (RT_DBG(fp) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
+      if ((RT_DBG(fp) & 2u) && active) {      // shortcut disabled: audit what it would have claimed
+        if (!lane_can && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
+        if (lane_full && total != 0.0f) atomicAdd(&C->dbg[1], 1ull);
+        if (lane_can && !lane_full) atomicAdd(&C->dbg[2], 1ull);
+        atomicAdd(&C->dbg[3], 1ull);
+      }
       const float T = total * inv_cells;
       const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)

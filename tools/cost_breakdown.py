@@ -22,12 +22,12 @@ for n_lights in (0, 1, 5):
     mats, surfs, lights = separate_objects(objs)
     cam.setup(W / H)
     with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as gs:
-        for n in (1, 5):
+        for n, depth in ((1, 3), (5, 3), (1, 0)):
             best = None
             for _ in range(3):
-                gs.render(cam, W, H, n, 3, precision="fp32", jitter=1234, flags=_lib.RT_FLAG_TIMING)
+                gs.render(cam, W, H, n, depth, precision="fp32", jitter=1234, flags=_lib.RT_FLAG_TIMING)
                 s = gs.last_stats
                 if best is None or s["shade_ms"] < best["shade_ms"]:
                     best = s
-            print(json.dumps({"lights": n_lights, "n_shadow": n, "shade_ms": round(best["shade_ms"], 3),
+            print(json.dumps({"lights": n_lights, "n_shadow": n, "depth": depth, "shade_ms": round(best["shade_ms"], 3),
                               "trace_ms": round(best["trace_ms"], 3), "hits": best["hits"]}))
