@@ -224,7 +224,8 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
 // speculatively while the node is being tested and the <= 8 record bounds of a leaf are fetched
 // together before any of them is tested.
 template <class NodeHit, class PrimMay, class OnPrim>
-__device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, PrimMay prim_may, OnPrim on_prim) {
+__device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, PrimMay prim_may, OnPrim on_prim,
+                                         uint32_t dbg_skip = 0) {
   const int n = ac.n_nodes;
   if (n <= 0) return;
   int i = 0;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, Prim
     const int nxt = i + 1;
     const BvhNode nx = ac.nodes[nxt < n ? nxt : i];
     if (node_hit(nd)) {
-      const int nj = nd.count();
+      const int nj = (dbg_skip & 16u) ? 0 : nd.count();
       if (nj > 0) {
         float4 b[8];
 #pragma unroll
@@ -241,6 +242,7 @@ __device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, Prim
         uint32_t cand = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) cand |= (j < nj && prim_may(b[j])) ? (1u << j) : 0u;
+        if (dbg_skip & 32u) cand = 0;
         while (cand) {
           const int j = __ffs((int)cand) - 1;
           cand &= cand - 1;

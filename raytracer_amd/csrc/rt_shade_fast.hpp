@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
                 if (RT_DBG(fp)) ++dbg_cands;
                 if (k < sc.nS) do_sphere(P[k]);
                 else if (HAS_BOX) do_box(P[k]);
-              });
+              }, RT_DBG(fp));
             if (RT_DBG(fp)) {
               atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], (unsigned long long)dbg_nodes);
               atomicAdd(&C->dbg[2], (unsigned long long)dbg_bounds); atomicAdd(&C->dbg[3], (unsigned long long)dbg_cands);
