@@ -303,6 +303,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
+  s->ds.all_opaque = s->all_opaque ? 1 : 0; s->ds.pad = 0;
   if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
   *out = s;
   return RT_OK;

@@ -59,6 +59,7 @@ struct DevScene {
   int32_t nM, nL;
   double bg[3];
   Accel ac;
+  int32_t all_opaque, pad;   // every surface material has transparency == 0
 };
 constexpr int MAT_STRIDE = 12;
 constexpr int LIGHT_STRIDE = 12;
@@ -195,21 +196,26 @@ __device__ __forceinline__ double box_hit(const Prim& b, d3 o, d3 d, d3* n_out) 
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
                                                 int* k_out, double plane_thr);
 __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
-                                          double plane_thr = HIT_EPS, const Accel* ac = nullptr) {
+                                          double plane_thr = HIT_EPS, const Accel* ac = nullptr,
+                                          uint32_t mask = 0xFFFFFFFFu) {
+  // mask: wave-uniform candidate set for records 0..31 (fan_cull); records >= 32 are always tested
   if (ac != nullptr && ac->n_nodes > 0) return nearest_accel(P, nS, nP, *ac, o, d, k_out, plane_thr);
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   int k = 0;
   for (int e = nS; k < e; ++k) {
+    if (k < 32 && !((mask >> k) & 1u)) continue;
     double t = sphere_t(P[k], o, d);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP; k < e; ++k) {
+    if (k < 32 && !((mask >> k) & 1u)) continue;
     double t = plane_t(P[k], o, d, plane_thr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP + nB; k < e; ++k) {
+    if (k < 32 && !((mask >> k) & 1u)) continue;
     double t = box_hit<false>(P[k], o, d, nullptr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
@@ -328,12 +334,12 @@ constexpr int SEQ_WALK_CAP = 1 << 16;
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
                                               int* queries, bool seq = false, double plane_thr = HIT_EPS,
-                                              const Accel* ac = nullptr) {
+                                              const Accel* ac = nullptr, uint32_t mask = 0xFFFFFFFFu) {
   double remaining = maxdist, trans = 1.0;
   const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
   for (int step = 0; step < cap; ++step) {
     if (seq && !(remaining > EPS)) break;                        // :303
-    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr, ac);
+    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr, ac, mask);
     ++*queries;
     if (!((t < remaining) && k >= 0)) break;                     // :269-272, :290-291
     trans *= mats[MAT_STRIDE * P[k].mat + 10];                   // :276-279
@@ -343,6 +349,70 @@ __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS
     remaining -= adv;
   }
   return trans;
+}
+
+// Conservative fp32 pre-pass of the exact shading code for one (hit, light) of a small scene
+// (<= 32 records).  All shadow segments of the light start at p and end within RL of Lp, so they lie
+// in the cone-like hull  { p + tau*tl + e : |e| <= tau*RL, 0 <= tau <= 1 }.
+//   act        wave-uniform set of records that can cross the hull for SOME lane: the walks test only
+//              these.  A record outside the set can only be hit beyond the light, which ends a walk
+//              exactly like "no hit" does (ray_tracer.py:269-272) -> results and query counts unchanged.
+//   lane_can   some record can cross this lane's hull.  If not, every walk of the lane does one query
+//              that finds nothing before the light and returns exactly 1.
+//   lane_full  all-opaque scenes: at the central segment's closest approach the whole hull cross-section
+//              lies inside one sphere, p and the light's samples lie outside it -> every walk's first
+//              query hits an opaque surface before the light and returns exactly 0.
+// The fp32 slack (1e-5 relative to the magnitudes involved) exceeds the rounding of this arithmetic by
+// two orders of magnitude; far hits, where |oc|^2 ~ |tl|^2 >> r^2, never get a lane_full claim.
+struct FanCull { uint32_t act; bool lane_can, lane_full; };
+__device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __restrict__ P, d3 p, d3 Lp, float RLin) {
+  FanCull fc; fc.act = 0u; fc.lane_can = false; fc.lane_full = false;
+  const float RL = RLin * 1.001f;
+  const float tx = (float)(Lp.x - p.x), ty = (float)(Lp.y - p.y), tz = (float)(Lp.z - p.z);
+  const float T0 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+  const float qa = T0 - RL * RL, rqa = 1.0f / qa, rT0 = 1.0f / T0;
+  int k = 0;
+  for (int e = sc.nS; k < e; ++k) {
+    const Prim& s = P[k];
+    const double ox = p.x - s.a[0], oy = p.y - s.a[1], oz = p.z - s.a[2];
+    const float cc = (float)(((ox * ox + oy * oy) + oz * oz) - s.a[4]);    // epsilon-carrying term from fp64
+    const float r = (float)s.a[3], r2 = (float)s.a[4];
+    const float A = fmaf((float)oz, tz, fmaf((float)oy, ty, (float)ox * tx));                 // oc.tl
+    const float qb = A - r * RL;
+    const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
+    const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), cc);               // min over tau of |oc + tau tl|^2 - (r + tau RL)^2
+    // every segment direction leaves the sphere: oc.ts >= A - RL*|oc| > 0 with the origin outside
+    const float ocn = sqrtf(fmaxf(cc + r2, 0.0f));
+    const bool away = (cc >= 0.0f) & (A - RL * ocn > 1e-5f * (fabsf(A) + ocn * sqrtf(T0) + 1e-3f));
+    const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc) + r2))) & !away;
+    fc.lane_can |= can;
+    if (__any(can)) fc.act |= 1u << k;
+    if (sc.all_opaque) {
+      const float ts = fminf(fmaxf(-A * rT0, 0.0f), 1.0f);
+      const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * A), cc + r2);       // |oc + ts*tl|^2
+      const float room = r * 0.999f - ts * RL;
+      const float lend2 = (cc + r2) + 2.0f * A + T0;                       // |oc + tl|^2: light centre to sphere centre
+      const bool trust = (fabsf(cc) < 1000.0f * r2) & (T0 < 1000.0f * r2) & (r > 0.1f);
+      fc.lane_full |= trust & (cc > 0.0f) & (room > 0.0f) & (dist2 < room * room) &
+                      (lend2 > (r + RL) * (r + RL) * 1.01f);
+    }
+  }
+  for (int e = sc.nS + sc.nP; k < e; ++k) {
+    const Prim& s = P[k];
+    const float num = (float)(s.a[3] - ((p.x * s.a[0] + p.y * s.a[1]) + p.z * s.a[2]));
+    const float D0 = fmaf((float)s.a[2], tz, fmaf((float)s.a[1], ty, (float)s.a[0] * tx));   // N.tl, |N| = 1
+    const float spread = RL * 1.001f + 1e-5f * (fabsf(D0) + sqrtf(T0));
+    // tau = num / (N.ts) in (0, 1) needs num and N.ts of the same sign; N.ts is within `spread` of D0
+    const bool can = num < 0.0f ? (D0 - spread <= 0.0f) : (num > 0.0f ? (D0 + spread >= 0.0f) : true);
+    fc.lane_can |= can;
+    if (k < 32 && __any(can)) fc.act |= 1u << k;
+  }
+  for (int e = sc.n; k < e; ++k) {               // boxes: always candidates
+    fc.lane_can = true;
+    if (k < 32) fc.act |= 1u << k;
+  }
+  if (!(T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; fc.act = 0xFFFFFFFFu; }   // light at the hit point
+  return fc;
 }
 
 // Camera.generate_all_rays / generate_rays_for_rows, camera.py:46-104: unit direction of pixel (x, y).

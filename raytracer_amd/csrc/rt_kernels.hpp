@@ -279,12 +279,25 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
     const double* lg = sc.lights + LIGHT_STRIDE * li;
     const d3 Lp = mk3(lg[0], lg[1], lg[2]);
     double T;
-    if (n_sh <= 1) {                                                               // :184-196
+    // small scenes: conservative candidate set + fully-lit / umbra shortcut (rt_device.hpp, fan_cull)
+    uint32_t cmask = 0xFFFFFFFFu;
+    bool shortcut = false;
+    if (sc.n <= 32 && (ac == nullptr || ac->n_nodes == 0)) {
+      const FanCull fc = fan_cull(sc, P, p, Lp, n_sh > 1 ? 0.7072f * (float)lg[8] : 0.0f);
+      cmask = fc.act;
+      if (!__any(fc.lane_can & !fc.lane_full)) {
+        shortcut = true;
+        T = fc.lane_full ? 0.0 : 1.0;                                              // n^2 terms of exactly 0 or 1
+        *queries += n_sh > 1 ? n_sh * n_sh : 1;                                    // one query per walk
+      }
+    }
+    if (shortcut) {
+    } else if (n_sh <= 1) {                                                               // :184-196
       d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
       double dist = norm3(tl);
       d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
       d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac);
+      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
     } else {
       d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
       double ldist = norm3(tl);
@@ -312,7 +325,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
           double dist = norm3(ts);
           d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
           d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac);
+          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
         }
       T = total / (double)(n_sh * n_sh);                                           // :243
     }
