@@ -11,7 +11,7 @@ The frame is fixed as N grows (strong scaling).  Rank 0 prints ONE JSON line.
 metric/value: Mrays/s, rays = radiance rays + shadow rays of the frame, whole job.
 roofline: the dominant kernel (k_shade_ls / k_shade_fast / k_shade_exact) — algorithmic flops of its launches
   (raytracer_amd/flops.py) / their summed duration, measured with HIP events on the
-  stream the kernels run on (rt_stats, RT_FLAG_TIMING) during the timed steps.  The bound is the
+  stream the kernels run on (rt_stats, RT_FLAG_TIMING) on every --timing-every-th frame of the timed steps.  The bound is the
   vector ALU (no MFMA-shaped work, HBM traffic is one framebuffer write), peak = 157.3 TFLOP/s fp32
   / 78.6 fp64 (MI355X_MICROARCH.md chip table).
 cpu_baseline: the C oracle (oracle/rt_oracle.c, a port of the reference's algorithm) timed on this
@@ -88,6 +88,8 @@ def main():
                     help="rows per interleaved block (0 = largest value <= 16 that gives every rank the same number of rows, else 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="bracket the kernels of every k-th timed frame with HIP events (the events cost ~3 %% of a 4K frame)")
     ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with a full-frame render on rank 0")
     args = ap.parse_args()
 
@@ -142,7 +144,10 @@ def main():
     tile = tiles[0]
     frame = torch.empty((H, W, 3), dtype=dtype, device=dev) if (world > 1 and rank == 0) else None
     scratch = new_scratch(tile, world) if (world > 1 and rank == 0) else None
-    flags = _lib.RT_FLAG_ASYNC | (0 if args.no_timing else _lib.RT_FLAG_TIMING)
+    every = max(1, args.timing_every)
+
+    def flags_of(k):
+        return _lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0)
     if pipelined:
         render_stream, comm_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         gs.set_stream(render_stream.cuda_stream)
@@ -152,6 +157,7 @@ def main():
 
     def step(stats):
         k = frame_no[0]; frame_no[0] += 1
+        flags = flags_of(k)
         if not pipelined:
             gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
                       part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
@@ -176,6 +182,7 @@ def main():
     for _ in range(args.warmup):
         step(_lib.Stats())
     gs.sync()
+    frame_no[0] = 0
     all_stats = [_lib.Stats() for _ in range(args.steps)]
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -209,9 +216,10 @@ def main():
         value = total_rays / (ms_per_step * 1e-3) / 1e6
         n_sph, n_pln, n_box = packed.counts
         # dominant kernel on this rank: shade launches of the timed steps
-        shade_ms = sum(s.shade_ms for s in all_stats) / args.steps
-        trace_ms = sum(s.trace_ms for s in all_stats) / args.steps
-        launches = max(last.shade_launches, 1)
+        timed = [s for k, s in enumerate(all_stats) if k % every == 0] if not args.no_timing else []
+        shade_ms = sum(s.shade_ms for s in timed) / max(len(timed), 1)     # frames bracketed with HIP events
+        trace_ms = sum(s.trace_ms for s in timed) / max(len(timed), 1)
+        launches = max(all_stats[0].shade_launches, 1)
         seg = max(int(last.segments), 0)
         flops_frame = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
                                          hits=int(last.hits), segments=seg)
@@ -229,7 +237,7 @@ def main():
                         "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
                         "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
-                        "launches_per_step": launches, "shade_ms_per_step": round(shade_ms, 4),
+                        "launches_per_step": launches, "frames_with_events": len(timed), "shade_ms_per_step": round(shade_ms, 4),
                         "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
         out = {
             "metric": "Mrays/s incl. shadow+secondary rays, pool.txt 4K" if args.workload == "pool4k"
@@ -244,7 +252,7 @@ def main():
                                       + (", frames pipelined 2 deep (gather k overlaps render k+1)" if pipelined else "")},
             "roofline": roofline,
         }
-        if world > 1:
+        if world > 1 and roofline is not None:
             roofline["traffic"] = None      # the PMC pass (profiles/) measured full-frame launches on one GPU
         if verify is not None:
             out["verify"] = verify
