@@ -209,7 +209,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
 
-  for (uint32_t iter = blockIdx.x; iter < n_iters; iter += gridDim.x) {
+  // Blocks take 256-hit chunks from a device counter (Counters::work_shade, zeroed per frame): chunk costs
+  // differ by several x (penumbra vs fully lit), and with a fraction of a frame per GPU there are only a
+  // few chunks per resident block, so a static round-robin leaves a long tail.
+  __shared__ uint32_t s_iter;
+  for (;;) {
+    if (threadIdx.x == 0) s_iter = atomicAdd(&C->work_shade[level], 1u);
+    __syncthreads();
+    const uint32_t iter = s_iter;
+    __syncthreads();                       // everyone has read s_iter before thread 0 overwrites it
+    if (iter >= n_iters) break;
     const uint32_t h = iter * BLOCK + threadIdx.x;
     const bool active = h < count;
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
