@@ -136,8 +136,10 @@ def main():
 
     tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
     dtype = torch.float32 if precision == "fp32" else torch.float64
-    # N > 1: frames are pipelined two deep — the gather of frame k (comm stream) overlaps the render of
-    # frame k+1 (render stream, into the other tile buffer).  RT_BENCH_PIPELINE=0 serialises them.
+    # N > 1: two frames are in flight — frames alternate between two scene handles (each with its own
+    # workspace, render stream and tile buffer), so the kernels of frame k+1 fill the tails of frame k's
+    # small launches, and the gather of frame k (comm stream) overlaps the render of frame k+1.
+    # RT_BENCH_PIPELINE=0 serialises everything on one stream (frame latency).
     pipelined = world > 1 and os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
     n_buf = 2 if pipelined else 1
     tiles = [torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev) for _ in range(n_buf)]
@@ -148,9 +150,13 @@ def main():
 
     def flags_of(k):
         return _lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0)
+    scenes = [gs]
     if pipelined:
-        render_stream, comm_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        gs.set_stream(render_stream.cuda_stream)
+        scenes.append(GpuScene(packed, device=local_rank))
+        render_streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        comm_stream = torch.cuda.Stream(dev)
+        for sc_, st_ in zip(scenes, render_streams):
+            sc_.set_stream(st_.cuda_stream)
         rendered = [torch.cuda.Event() for _ in range(2)]
         tile_free = [None, None]
     frame_no = [0]
@@ -165,10 +171,11 @@ def main():
                 gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             return
         b = k & 1
+        render_stream = render_streams[b]
         if tile_free[b] is not None:
             render_stream.wait_event(tile_free[b])          # the gather of frame k-2 has read this tile
-        gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
-                  part=rank, n_parts=world, out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
+        scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                         part=rank, n_parts=world, out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
         rendered[b].record(render_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[b])
@@ -181,7 +188,8 @@ def main():
 
     for _ in range(args.warmup):
         step(_lib.Stats())
-    gs.sync()
+    for sc_ in scenes:
+        sc_.sync()
     frame_no[0] = 0
     all_stats = [_lib.Stats() for _ in range(args.steps)]
     barrier(); torch.cuda.synchronize()
@@ -190,7 +198,8 @@ def main():
         step(s)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
-    gs.sync()   # folds counters / event timings into the rt_stats of the timed steps
+    for sc_ in scenes:
+        sc_.sync()   # folds counters / event timings into the rt_stats of the timed steps
 
     # whole-job numbers: max time over ranks, rays summed over ranks
     last = all_stats[-1]
@@ -206,6 +215,7 @@ def main():
     verify = None
     if args.verify and world > 1 and rank == 0:
         full = torch.empty((H, W, 3), dtype=dtype, device=dev)
+        torch.cuda.synchronize()
         gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=full.data_ptr())
         torch.cuda.synchronize()
         verify = {"max_abs_diff_vs_single_gpu_frame": float((full - frame).abs().max())}
@@ -249,7 +259,7 @@ def main():
             "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
                        "shadow_rays": int(shadow), "row_blocks": args.block_rows,
                        "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")
-                                      + (", frames pipelined 2 deep (gather k overlaps render k+1)" if pipelined else "")},
+                                      + (", 2 frames in flight (two streams; gather k overlaps render k+1)" if pipelined else "")},
             "roofline": roofline,
         }
         if world > 1 and roofline is not None:
@@ -262,7 +272,8 @@ def main():
             out["parity_check"] = parity
         print(json.dumps(out), flush=True)
 
-    gs.close()
+    for sc_ in scenes:
+        sc_.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,3 +40,17 @@ with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as gs:
             gs.sync()
         print(f"N={n}: trace {s.trace_ms:.3f} ms in {s.trace_launches} launches, shade {s.shade_ms:.3f} ms in {s.shade_launches}, "
               f"other {s.other_ms:.3f}, first start -> last end {s.total_ms:.3f} ms; level hits {list(s.level_hits[:depth + 1])}")
+# two scene handles (own streams / workspaces), frames alternating between them: tails of one frame's
+# small launches are filled by the other frame's kernels
+buf2 = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(buf2), W * H * 12) == 0
+with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as a, GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as b:
+    for n in (1, 2, 4, 8):
+        br = [x for x in range(16, 3, -1) if H % x == 0 and (H // x) % n == 0][0]
+        def go(frames):
+            for k in range(frames):
+                (a if k % 2 == 0 else b).render(cam, W, H, n_sh, depth, precision=precision, jitter=1234, block_rows=br, part=0, n_parts=n,
+                                                out_ptr=(buf if k % 2 == 0 else buf2).value, flags=_lib.RT_FLAG_ASYNC)
+            a.sync(); b.sync()
+        go(4)
+        t0 = time.perf_counter(); go(40); ms = (time.perf_counter() - t0) / 40 * 1e3
+        print(f"two frames in flight, N={n} part 0: {ms:.3f} ms/frame")
