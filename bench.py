@@ -252,7 +252,10 @@ def main():
                     traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": ("k_shade_ls (k_shade_fast for large scenes)" if precision == "fp32" else "k_shade_exact"),
+            small = n_sph <= 8 and n_pln <= 2 and n_box <= 4
+            roofline = {"bound": "valu", "kernel": (("k_shade_ls" if small else "k_shade_fast") if precision == "fp32" else "k_shade_exact"),
+                        "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d) (every query tests every surface); the kernels' "
+                                      "conservative culling skips part of that work, so achieved is an effective rate",
                         "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
                         "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
