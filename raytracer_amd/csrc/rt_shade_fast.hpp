@@ -123,7 +123,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             for (int s = 0; s < CH; ++s) {
               const float b = fmaf(oc.z, dz[s], fmaf(oc.y, dy[s], oc.x * dx[s]));   // oc.d  (a = d.d = 1)
               const float sq = raw_sqrt(fmaf(b, b, -cc));               // NaN on a miss: both tests fail
-              const float t1 = -b - sq, t2 = sq - b;
+              // roots {q, cc/q} with q the root that does not cancel: the other one can be the crossing of
+              // the hit's own sphere at t' ~ 1e-6/cos, which has to be compared with the 2e-6 bound
+              const float t1 = b < 0.0f ? sq - b : -b - sq;
+              const float t2 = cc * raw_rcp(t1);
               const bool in1 = (t1 > T_LO) & (t1 < md[s]);
               const bool in2 = (t2 > T_LO) & (t2 < md[s]);
               if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }

@@ -25,7 +25,9 @@
 //    two differ only when the light is behind the hit's own surface, where diffuse is zero.  For an
 //    own PLANE the reference lets such rays through when |n.d| >= 0.5 (the own-surface hit at
 //    t = 1e-6/|n.d| fails its t > 1e-6 test after the 1e-6 origin shift); that is reproduced exactly
-//    by a per-wave slow path (PLANE_LO) taken only when some lane has that configuration.
+//    by a per-wave slow path (LO) taken only when some lane has that configuration; the same path
+//    applies the bound to the hit's own sphere / box when the outcome can depend on it (light inside
+//    the own primitive, or transparency anywhere in the scene).
 #pragma once
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
@@ -67,12 +69,20 @@ struct LsPrims {
 // stream (measured: 170 SALU vs 134 VALU instructions per pair, no faster than k_shade_small).
 // NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6, 8; unused slots hold A = B = C = 0,
 // cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
-template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool PLANE_LO>
+template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool LO>
 __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
                                               const float2* __restrict__ cells, int n_cells, JitKey key, float cell32,
-                                              f3 tl, f3 right, f3 up, float T0, float T1, float T2) {
+                                              f3 tl, f3 right, f3 up, float T0, float T1, float T2, int own = -1) {
   float total = 0.0f;
   const int n_pairs = (n_cells + 1) >> 1;
+  // LO: coefficients of the lane's OWN sphere (selected once; the slow path is rare and must not
+  // raise the kernel's register budget, so only the own sphere gets the two-root treatment)
+  float oA = 0.0f, oB = 0.0f, oC = 0.0f, occ = 1.0f, otau = 1.0f;
+  if (LO) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (own == k) { oA = pr.A[k]; oB = pr.B[k]; oC = pr.C[k]; occ = pr.cc[k]; if (!OPAQUE) otau = pr.tauS[k]; }
+  }
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
   float2 nb0 = cells[0], nb1 = cells[n_cells > 1 ? 1 : 0];
@@ -98,7 +108,18 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
       if (!(act & (1u << k))) continue;                                     // culled for this (wave, light)
       const v2f bt = pk_fma(oj, splat(pr.C[k]), pk_fma(oi, splat(pr.B[k]), splat(pr.A[k])));   // oc.ts
       const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(pr.cc[k]))));                         // NaN on a miss
-      if (OPAQUE) {
+      if (LO) {                                                             // own sphere: handled after the loop
+        if (OPAQUE) {
+          v2f u = pk_fma(splat(pr.sgn[k]), sq, -bt);
+          if (own == k) u = splat(-1.0f);
+          m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y));
+        } else {
+          const v2f u1 = -bt - sq, u2 = sq - bt;
+          const float ta = own == k ? 1.0f : pr.tauS[k];
+          tr.x *= in_open(u1.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u1.y, d2.y) ? ta : 1.0f;
+          tr.x *= in_open(u2.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u2.y, d2.y) ? ta : 1.0f;
+        }
+      } else if (OPAQUE) {
         const v2f u = pk_fma(splat(pr.sgn[k]), sq, -bt);                    // far root iff origin inside
         m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y));
       } else {
@@ -108,13 +129,34 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
         tr.x *= in_open(u2.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u2.y, d2.y) ? ta : 1.0f;
       }
     }
+    if (LO) {
+      // The lane's own sphere with the reference's lower bound t' = u/|ts| > 2e-6 on both roots
+      // (u^2 > 4e-12 |ts|^2): a shadow ray that crosses the surface it starts on does so at
+      // t' = 1e-6/cos, which the reference does not see when cos >= 0.5 (origin shift 1e-6 + hit threshold
+      // 1e-6).  The small root is formed as |ts|^2 cc / (large root) to avoid the cancellation of
+      // -bt -+ sqrt(..) at that scale.  occ = 1 (no own sphere): negative discriminant, nothing happens.
+      const v2f bt = pk_fma(oj, splat(oC), pk_fma(oi, splat(oB), splat(oA)));
+      const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(occ))));
+      v2f u2;
+      u2.x = bt.x < 0.0f ? sq.x - bt.x : -bt.x - sq.x; u2.y = bt.y < 0.0f ? sq.y - bt.y : -bt.y - sq.y;
+      const v2f u1 = d2 * splat(occ) * pk_rcp(u2);                          // u1 * u2 = |ts|^2 cc
+      const v2f lo2 = d2 * splat(T_LO * T_LO);
+      const bool a0 = in_open(u1.x, d2.x) & (u1.x * u1.x > lo2.x), a1 = in_open(u1.y, d2.y) & (u1.y * u1.y > lo2.y);
+      const bool b0 = in_open(u2.x, d2.x) & (u2.x * u2.x > lo2.x), b1 = in_open(u2.y, d2.y) & (u2.y * u2.y > lo2.y);
+      if (OPAQUE) {
+        m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1;                 // 0 = "blocked" for the final compare
+      } else {
+        tr.x *= a0 ? otau : 1.0f; tr.y *= a1 ? otau : 1.0f;
+        tr.x *= b0 ? otau : 1.0f; tr.y *= b1 ? otau : 1.0f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
       if (act & (0x10000u << k)) {
         const v2f den = pk_fma(oj, splat(pr.D2[k]), pk_fma(oi, splat(pr.D1[k]), splat(pr.D0[k])));   // N.ts
         const v2f tau = splat(pr.num[k]) * pk_rcp(den);                    // den == 0 -> inf/NaN -> miss
         v2f u = tau * d2;                                                   // same scale as the sphere roots
-        if (PLANE_LO) {   // exact lower bound of the reference: tau*|ts| > 2e-6 (own plane, light behind it)
+        if (LO) {   // exact lower bound of the reference: tau*|ts| > 2e-6 (own plane, light behind it)
           const v2f t2 = tau * u;
           u.x = t2.x > T_LO * T_LO ? u.x : -1.0f; u.y = t2.y > T_LO * T_LO ? u.y : -1.0f;
         }
@@ -138,7 +180,17 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
             tn.y = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
             tf.x = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
             tf.y = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
-            if (OPAQUE) {
+            if (LO) {                                                      // see the sphere slow path
+              const float lo0 = T_LO * T_LO * raw_rcp(d2.x), lo1 = T_LO * T_LO * raw_rcp(d2.y);   // tau^2 > 4e-12 / |ts|^2
+              const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
+              const bool a0 = ok0 & in_open(tn.x, 1.0f) & (tn.x * tn.x > lo0), a1 = ok1 & in_open(tn.y, 1.0f) & (tn.y * tn.y > lo1);
+              const bool b0 = ok0 & in_open(tf.x, 1.0f) & (tf.x * tf.x > lo0), b1 = ok1 & in_open(tf.y, 1.0f) & (tf.y * tf.y > lo1);
+              if (OPAQUE) { m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1; }
+              else {
+                const float ta = pr.tauB[k];
+                tr.x *= a0 ? ta : 1.0f; tr.y *= a1 ? ta : 1.0f; tr.x *= b0 ? ta : 1.0f; tr.y *= b1 ? ta : 1.0f;
+              }
+            } else if (OPAQUE) {
               // entry root, or the exit root when the origin is inside; -1 (never in range) if the slabs miss
               const float t0 = tn.x <= tf.x ? (pr.binside[k] ? tf.x : tn.x) : -1.0f;
               const float t1 = tn.y <= tf.y ? (pr.binside[k] ? tf.y : tn.y) : -1.0f;
@@ -168,6 +220,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   __shared__ float2 s_cells[LS_MAX_CELLS];
   __shared__ float s_lightf[LS_MAX_LIGHTS][LIGHT_STRIDE];    // lights as fp32 (the shadow origin's epsilon lives in cc / num)
   __shared__ float4 s_sphf[MAXS];                             // sphere centres + radii as fp32
+  // per light: spheres that (some sample of) the light may be inside of / outside of — hit independent
+  __shared__ uint32_t s_lin[LS_MAX_LIGHTS], s_lout[LS_MAX_LIGHTS];
   __shared__ double s_matd[LS_MAX_MATS][MAT_STRIDE];
   // exact fp64 geometry of each lane's hit, parked for the spawn step (hit point, normal, ray direction,
   // weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
@@ -195,6 +249,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const float cell = radius / (float)n_side, half = -0.5f * radius;
       const int i = c / n_side, j = c - i * n_side;
       s_cells[e] = n_sh > 1 ? make_float2(fmaf(cell, (float)i, half), fmaf(cell, (float)j, half)) : make_float2(0.0f, 0.0f);
+    }
+    for (int li = threadIdx.x; li < sc.nL; li += BLOCK) {
+      const float RL = n_sh > 1 ? 0.7072f * (float)sc.lights[LIGHT_STRIDE * li + 8] * 1.001f : 0.0f;
+      uint32_t in_ = 0u, out_ = 0u;
+      for (int k = 0; k < sc.nS && k < MAXS; ++k) {
+        const double dx = sc.lights[LIGHT_STRIDE * li] - sc.prims[k].a[0], dy = sc.lights[LIGHT_STRIDE * li + 1] - sc.prims[k].a[1],
+                     dz = sc.lights[LIGHT_STRIDE * li + 2] - sc.prims[k].a[2];
+        const float l2 = (float)((dx * dx + dy * dy) + dz * dz), r = (float)sc.prims[k].a[3];
+        const float rin = fmaxf(r - RL, 0.0f);
+        if (l2 < (r + RL) * (r + RL) * 1.001f) in_ |= 1u << k;
+        if (l2 > rin * rin * 0.999f) out_ |= 1u << k;
+      }
+      s_lin[li] = in_; s_lout[li] = out_;
     }
     __syncthreads();
   }
@@ -256,6 +323,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       }
     }
     bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
+    uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
       a_cc[k] = 1.0f; a_sgn[k] = -1.0f;
@@ -265,6 +333,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         a_cc[k] = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
         a_sgn[k] = a_cc[k] < 0.0f ? 1.0f : -1.0f;
         near_scene &= fabsf(a_cc[k]) < 1000.0f * (float)s_.a[4];
+        if (own == k) { own_in_bit = a_cc[k] < 0.0f ? 1u << k : 0u; own_out_bit = a_cc[k] < 0.0f ? 0u : 1u << k; }
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -327,9 +396,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
           a_D0[k] = dotf(N, tl); a_D1[k] = dotf(N, right); a_D2[k] = dotf(N, up);
         }
       }
-      // Slow path only if some lane's own surface is a plane with the light (partly) behind it.
+      // Slow path (exact lower bound 2e-6 on every crossing) only if some lane needs it: the light is
+      // (partly) behind the hit's own surface AND the outcome can depend on the own-surface crossing the
+      // reference does not see — always for an own plane and in scenes with transparency; in all-opaque
+      // scenes an own sphere / box blocks through its far side anyway unless the light is on its other side.
       const float nt = dotf(nf, tl);
-      const bool need_lo = own_is_plane & (nt < 0.71f * radius);
+      const bool behind = nt < 0.71f * radius;
+      // the hit point and (some sample of) the light possibly on different sides of the hit's own sphere /
+      // box: then the only crossing between them is the one at the hit point itself
+      bool own_light_inside = ((own_out_bit & s_lin[li]) | (own_in_bit & s_lout[li])) != 0u;
       // Conservative per-(wave, light) culling: a primitive is tested only if it can cross the
       // shadow segment of SOME sample of this light for SOME lane of the wave (results unchanged).
       // Every sample lies within RL of the light centre, so the segment p -> sample stays within RL
@@ -374,6 +449,17 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         // dist2 above is a difference of terms as large as T0 and |oc|^2: its fp32 cancellation error
         // ~4e-7 (|cc| + r^2 + T0) stays below the 0.2 % margin of `room` only for hits near the scene
         lane_full &= near_scene & (T0 < umbra_t0_max);
+        if (OPAQUE && MAXB > 0) {
+#pragma unroll
+          for (int k = 0; k < MAXB; ++k)      // same for the hit's own box (light vs the box grown / shrunk by RL)
+            if (k < nB) {
+              const float g_ = a_binside[k] ? -RL : RL;
+              const bool in_ = (a_blo[k][0] - g_ < tl.x) & (tl.x < a_bhi[k][0] + g_) & (a_blo[k][1] - g_ < tl.y) &
+                               (tl.y < a_bhi[k][1] + g_) & (a_blo[k][2] - g_ < tl.z) & (tl.z < a_bhi[k][2] + g_);
+              own_light_inside |= (own == nS + nP + k) & (a_binside[k] ? !in_ : in_);
+            }
+        }
+        lane_full &= !own_light_inside;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
           if (k < nP) {
@@ -394,9 +480,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         // (all n^2 terms are exactly 1) or in the umbra of one opaque sphere (all terms exactly 0).
         total = lane_full ? 0.0f : (float)n_cells;
         if (RT_DBG(fp) && lane == 0) atomicAdd(&C->queries, 1ull);
-      } else if ((RT_DBG(fp) & 4u) || __any(need_lo))
+      } else if ((RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true)))
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
-                                                                   T0, T1, T2);
+                                                                   T0, T1, T2, own);
       else
         total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                     T0, T1, T2);
@@ -426,7 +512,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       spc1 = fmaf(ks1 * lg[4], s2, spc1);
       spc2 = fmaf(ks2 * lg[5], s2, spc2);
     }
-    (void)own;
 
     // ------------------------------------------------- phase 3: accumulate, spawn children -----
     if (active) {
