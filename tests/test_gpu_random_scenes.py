@@ -16,7 +16,7 @@ def _q(img):
     return quantize_u8(img).astype(int)
 
 
-def random_scene_text(seed, opaque):
+def random_scene_text(seed, opaque, big=False):
     rng = np.random.default_rng(seed)
     n_mat = int(rng.integers(2, 6))
     lines = []
@@ -34,6 +34,8 @@ def random_scene_text(seed, opaque):
         n_box = 0                      # exercises the sphere-only small-scene kernels
     if seed % 5 == 1:
         n_sph += 9                     # beyond the small-scene limits -> general kernels
+    if big:                            # > 128 surfaces -> culling hierarchy
+        n_sph += int(rng.integers(100, 400)); n_box += int(rng.integers(30, 120))
     kinds = ["sph"] * n_sph + ["pln"] * n_pln + ["box"] * n_box
     rng.shuffle(kinds)
     for kd in kinds:
@@ -88,3 +90,25 @@ def test_random_scene_sequential_and_numpy_stream(oracle, seed):
     img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("numpy", seed), verbose=False)
     ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("numpy", seed))
     assert rel_err(img, ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_large_scene_through_the_hierarchy(oracle, seed):
+    """> 128 surfaces: nearest hits and shadow walks go through the culling hierarchy; overlapping and
+    nested primitives, lights inside primitives, transparent materials."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.render import render_hip
+    text = random_scene_text(7000 + seed, seed % 2 == 0, big=True)
+    cam, st, objs = parse_scene_text(text)
+    mats, surfs, lights = separate_objects(objs)
+    assert len(surfs) > 128
+    W, H = 48, 32
+    stats = {}
+    img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), stats=stats, verbose=False)
+    ref, ost = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), return_stats=True)
+    for k in ("rays", "hits", "shadow_rays", "segments"):
+        assert stats[k] == ost[k], (k, stats[k], ost[k])
+    assert rel_err(img, ref).max() < 1e-9
+    img32 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False)
+    d8 = np.abs(_q(img32) - _q(ref))
+    assert (d8 <= 1).mean() >= 0.99, float((d8 <= 1).mean())
