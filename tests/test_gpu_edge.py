@@ -119,3 +119,39 @@ def test_numpy_stream_jitter_on_overflow_scene(oracle):
     img, ref, stats, ostats = _both(text, 24, 16, oracle, "fp64", ("numpy", 77))
     assert stats["batches"] == ostats["batches"] and stats["rays"] == ostats["rays"]
     assert rel_err(img, ref).max() < 1e-12
+
+
+def test_many_async_frames_and_two_scenes_in_flight(oracle):
+    """RT_FLAG_ASYNC: 60 frames enqueued without a sync (the library folds finished frames itself when
+    48 are pending), alternating between two scene handles with their own streams; every frame's stats
+    and both final images must equal the blocking render (to the rounding of the atomic accumulation order)."""
+    import ctypes
+    from raytracer_amd import _lib, load_scene
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene
+    cam, st, mats, surfs, lights = load_scene("scenes/original.txt", 2, 3)
+    W, H = 160, 90
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    hip = ctypes.CDLL("libamdhip64.so")
+    bufs = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for b in bufs:
+        assert hip.hipMalloc(ctypes.byref(b), W * H * 3 * 4) == 0
+    try:
+        with GpuScene(packed) as a, GpuScene(packed) as b:
+            ref = a.render(cam, W, H, 2, 3, precision="fp32", jitter=5)
+            ref_stats = dict(a.last_stats)
+            stats = [_lib.Stats() for _ in range(60)]
+            for k, s in enumerate(stats):
+                (a if k % 2 == 0 else b).render(cam, W, H, 2, 3, precision="fp32", jitter=5, out_ptr=bufs[k % 2].value,
+                                                flags=_lib.RT_FLAG_ASYNC, stats=s)
+            a.sync(); b.sync()
+            for s in stats:
+                assert (s.rays, s.hits, s.shadow_rays) == (ref_stats["rays"], ref_stats["hits"], ref_stats["shadow_rays"])
+            for buf in bufs:
+                out = np.empty((H, W, 3), dtype=np.float32)
+                assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), buf, out.nbytes, 2) == 0   # device -> host
+                assert np.abs(out - ref).max() < 2e-6      # float atomics: accumulation order of a pixel's child rays
+    finally:
+        for b in bufs:
+            hip.hipFree(b)
