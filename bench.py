@@ -252,7 +252,7 @@ def main():
                     traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
                 except Exception:
                     traffic = None
-            small = n_sph <= 8 and n_pln <= 2 and n_box <= 4
+            small = n_pln <= 2 and ((n_box == 0 and n_sph <= 6) or (0 < n_box <= 4 and n_sph <= 4))
             roofline = {"bound": "valu", "kernel": (("k_shade_ls" if small else "k_shade_fast") if precision == "fp32" else "k_shade_exact"),
                         "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d) (every query tests every surface); the kernels' "
                                       "conservative culling skips part of that work, so achieved is an effective rate",

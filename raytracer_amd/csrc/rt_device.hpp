@@ -193,29 +193,36 @@ __device__ __forceinline__ double box_hit(const Prim& b, d3 o, d3 d, d3* n_out) 
 // find_nearest_intersection_batch, ray_tracer.py:112-127.  The reference walks the surface list in
 // file order and replaces on a strict '<'; on the type-sorted records that is the lexicographic
 // minimum of (t, orig).  Returns t (INF = miss) and the *sorted* record index (-1 = miss).
+// Wave-uniform candidate set over the first 128 records (fan_cull); records >= 128 always count as set.
+struct PrimMask {
+  unsigned long long lo, hi;
+  __device__ __forceinline__ bool has(int k) const { return k >= 128 || (((k < 64) ? (lo >> k) : (hi >> (k - 64))) & 1ull); }
+  __device__ __forceinline__ void set(int k) { if (k < 64) lo |= 1ull << k; else if (k < 128) hi |= 1ull << (k - 64); }
+};
+
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
                                                 int* k_out, double plane_thr);
 __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
                                           double plane_thr = HIT_EPS, const Accel* ac = nullptr,
-                                          uint32_t mask = 0xFFFFFFFFu) {
-  // mask: wave-uniform candidate set for records 0..31 (fan_cull); records >= 32 are always tested
+                                          const PrimMask* mask = nullptr) {
+  // mask: wave-uniform candidate set (fan_cull), nullptr = every record
   if (ac != nullptr && ac->n_nodes > 0) return nearest_accel(P, nS, nP, *ac, o, d, k_out, plane_thr);
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   int k = 0;
   for (int e = nS; k < e; ++k) {
-    if (k < 32 && !((mask >> k) & 1u)) continue;
+    if (mask != nullptr && !mask->has(k)) continue;
     double t = sphere_t(P[k], o, d);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP; k < e; ++k) {
-    if (k < 32 && !((mask >> k) & 1u)) continue;
+    if (mask != nullptr && !mask->has(k)) continue;
     double t = plane_t(P[k], o, d, plane_thr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP + nB; k < e; ++k) {
-    if (k < 32 && !((mask >> k) & 1u)) continue;
+    if (mask != nullptr && !mask->has(k)) continue;
     double t = box_hit<false>(P[k], o, d, nullptr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
@@ -334,7 +341,7 @@ constexpr int SEQ_WALK_CAP = 1 << 16;
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
                                               int* queries, bool seq = false, double plane_thr = HIT_EPS,
-                                              const Accel* ac = nullptr, uint32_t mask = 0xFFFFFFFFu) {
+                                              const Accel* ac = nullptr, const PrimMask* mask = nullptr) {
   double remaining = maxdist, trans = 1.0;
   const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
   for (int step = 0; step < cap; ++step) {
@@ -351,8 +358,8 @@ __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS
   return trans;
 }
 
-// Conservative fp32 pre-pass of the exact shading code for one (hit, light) of a small scene
-// (<= 32 records).  All shadow segments of the light start at p and end within RL of Lp, so they lie
+// Conservative fp32 pre-pass of the shading code for one (hit, light) of a scene without hierarchy
+// (<= 128 records, the LDS-staged scenes).  All shadow segments of the light start at p and end within RL of Lp, so they lie
 // in the cone-like hull  { p + tau*tl + e : |e| <= tau*RL, 0 <= tau <= 1 }.
 //   act        wave-uniform set of records that can cross the hull for SOME lane: the walks test only
 //              these.  A record outside the set can only be hit beyond the light, which ends a walk
@@ -364,9 +371,9 @@ __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS
 //              query hits an opaque surface before the light and returns exactly 0.
 // The fp32 slack (1e-5 relative to the magnitudes involved) exceeds the rounding of this arithmetic by
 // two orders of magnitude; far hits, where |oc|^2 ~ |tl|^2 >> r^2, never get a lane_full claim.
-struct FanCull { uint32_t act; bool lane_can, lane_full; };
+struct FanCull { PrimMask act; bool lane_can, lane_full; };
 __device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __restrict__ P, d3 p, d3 Lp, float RLin) {
-  FanCull fc; fc.act = 0u; fc.lane_can = false; fc.lane_full = false;
+  FanCull fc; fc.act.lo = fc.act.hi = 0ull; fc.lane_can = false; fc.lane_full = false;
   const float RL = RLin * 1.001f;
   const float tx = (float)(Lp.x - p.x), ty = (float)(Lp.y - p.y), tz = (float)(Lp.z - p.z);
   const float T0 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
@@ -386,7 +393,7 @@ __device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __re
     const bool away = (cc >= 0.0f) & (A - RL * ocn > 1e-5f * (fabsf(A) + ocn * sqrtf(T0) + 1e-3f));
     const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc) + r2))) & !away;
     fc.lane_can |= can;
-    if (__any(can)) fc.act |= 1u << k;
+    if (__any(can)) fc.act.set(k);
     if (sc.all_opaque) {
       const float ts = fminf(fmaxf(-A * rT0, 0.0f), 1.0f);
       const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * A), cc + r2);       // |oc + ts*tl|^2
@@ -405,13 +412,24 @@ __device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __re
     // tau = num / (N.ts) in (0, 1) needs num and N.ts of the same sign; N.ts is within `spread` of D0
     const bool can = num < 0.0f ? (D0 - spread <= 0.0f) : (num > 0.0f ? (D0 + spread >= 0.0f) : true);
     fc.lane_can |= can;
-    if (k < 32 && __any(can)) fc.act |= 1u << k;
+    if (__any(can)) fc.act.set(k);
   }
-  for (int e = sc.n; k < e; ++k) {               // boxes: always candidates
-    fc.lane_can = true;
-    if (k < 32) fc.act |= 1u << k;
+  for (int e = sc.n; k < e; ++k) {               // boxes: hull against the bounding sphere (centre, half diagonal)
+    const Prim& b = P[k];
+    const float cx = (float)(0.5 * (b.a[0] + b.a[3]) - p.x), cy = (float)(0.5 * (b.a[1] + b.a[4]) - p.y),
+                cz = (float)(0.5 * (b.a[2] + b.a[5]) - p.z);                                  // box centre - p = -oc
+    const float hx = (float)(b.a[3] - b.a[0]), hy = (float)(b.a[4] - b.a[1]), hz = (float)(b.a[5] - b.a[2]);
+    const float r = 0.5f * sqrtf(fmaf(hz, hz, fmaf(hy, hy, hx * hx))) * 1.0001f + 1e-5f;
+    const float oc2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+    const float A = -fmaf(cz, tz, fmaf(cy, ty, cx * tx));                                     // oc.tl
+    const float qb = A - r * RL;
+    const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
+    const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), oc2 - r * r);
+    const bool can = (qa <= 0.0f) | (g <= 1e-5f * (T0 + oc2 + r * r));
+    fc.lane_can |= can;
+    if (__any(can)) fc.act.set(k);
   }
-  if (!(T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; fc.act = 0xFFFFFFFFu; }   // light at the hit point
+  if (!(T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; fc.act.lo = fc.act.hi = ~0ull; }   // light at the hit point
   return fc;
 }
 

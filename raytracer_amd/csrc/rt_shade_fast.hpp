@@ -92,7 +92,18 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
         const float half = -0.5f * radius;
         const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
         float total = 0.0f;
-        for (int c = 0; c < n_chunks; ++c) {
+        // LDS-staged scenes (<= 128 records): conservative candidate set of this (wave, light) and the
+        // fully-lit / umbra shortcut (rt_device.hpp, fan_cull) — the sample blocks below run only for
+        // records whose bound can touch some lane's shadow fan.
+        PrimMask cand; cand.lo = cand.hi = ~0ull;
+        bool lane_lit = false, lane_dark = false, skip_samples = false;
+        if (LDS_SCENE) {
+          const FanCull fc = fan_cull(sc, P, p, mk3(lg[0], lg[1], lg[2]), n_sh > 1 ? 0.7072f * radius : 0.0f);
+          cand = fc.act; lane_lit = !fc.lane_can; lane_dark = fc.lane_full;
+          skip_samples = !(RT_DBG(fp) & 2u) && !__any(fc.lane_can & !fc.lane_full);
+        }
+        if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
+        for (int c = 0; c < (skip_samples ? 0 : n_chunks); ++c) {
           float dx[CH], dy[CH], dz[CH], md[CH], tr[CH];
           float ix[HAS_BOX ? CH : 1], iy[HAS_BOX ? CH : 1], iz[HAS_BOX ? CH : 1];
 #pragma unroll
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             }
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
+            if (!cand.has(k)) continue;
             const Prim& s_ = P[k];
             const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
             const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
@@ -209,12 +221,20 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
               atomicAdd(&C->dbg[2], (unsigned long long)dbg_bounds); atomicAdd(&C->dbg[3], (unsigned long long)dbg_cands);
             }
           } else {
-            for (int k = 0; k < sc.nS; ++k) do_sphere(P[k]);
+            for (int k = 0; k < sc.nS; ++k)
+              if (cand.has(k)) do_sphere(P[k]);
             if (HAS_BOX)
-              for (int k = sc.nS + sc.nP, e = sc.n; k < e; ++k) do_box(P[k]);
+              for (int k = sc.nS + sc.nP, e = sc.n; k < e; ++k)
+                if (cand.has(k)) do_box(P[k]);
           }
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
+        }
+        if ((RT_DBG(fp) & 2u) && LDS_SCENE) {      // audit build, shortcut disabled: check what it would have claimed
+          if (lane_lit && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
+          if (lane_dark && total != 0.0f) atomicAdd(&C->dbg[1], 1ull);
+          if (!lane_lit && !lane_dark) atomicAdd(&C->dbg[2], 1ull);
+          atomicAdd(&C->dbg[3], 1ull);
         }
         const float T = total * inv_cells;
         const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                       // ray_tracer.py:543

@@ -67,7 +67,7 @@ struct LsPrims {
 // (v_min_u32 / v_min3_u32); the cell is blocked iff min_bits < bits(|ts|^2) (see in_open).  A
 // compare per test would put ~3 SALU mask operations per VALU compare into the wave's instruction
 // stream (measured: 170 SALU vs 134 VALU instructions per pair, no faster than k_shade_small).
-// NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6, 8; unused slots hold A = B = C = 0,
+// NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6; unused slots hold A = B = C = 0,
 // cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
 template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool LO>
 __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
 }
 
 #ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)
-// Scenes served: up to 8 spheres + 2 planes without boxes, or up to 4 spheres + 2 planes + 4 boxes,
+// Scenes served: up to 6 spheres + 2 planes without boxes, or up to 4 spheres + 2 planes + 4 boxes,
 // any shadow grid with lights * n^2 <= LS_MAX_CELLS.  Returns false -> caller uses another kernel.
 static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
                             RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
@@ -592,7 +592,8 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
     if (ds.nS <= 2) RT_LS(2, 2, 0);
     if (ds.nS <= 4) RT_LS(4, 2, 0);
     if (ds.nS <= 6) RT_LS(6, 2, 0);
-    if (ds.nS <= 8) RT_LS(8, 2, 0);
+    // 7-8 spheres: the 8-sphere instantiation needs > 256 VGPRs (1 wave/SIMD) and measured slower than
+    // k_shade_fast with its candidate sets (pool + 2 spheres at 4K: 4.5 ms vs 3.9 ms)
   } else if (ds.nB <= 4) {
     if (ds.nS <= 2) RT_LS(2, 2, 4);
     if (ds.nS <= 4) RT_LS(4, 2, 4);
