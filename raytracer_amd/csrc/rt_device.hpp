@@ -198,31 +198,32 @@ struct PrimMask {
   unsigned long long lo, hi;
   __device__ __forceinline__ bool has(int k) const { return k >= 128 || (((k < 64) ? (lo >> k) : (hi >> (k - 64))) & 1ull); }
   __device__ __forceinline__ void set(int k) { if (k < 64) lo |= 1ull << k; else if (k < 128) hi |= 1ull << (k - 64); }
+  __device__ __forceinline__ static PrimMask all() { PrimMask m; m.lo = m.hi = ~0ull; return m; }
 };
 
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
                                                 int* k_out, double plane_thr);
 __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
                                           double plane_thr = HIT_EPS, const Accel* ac = nullptr,
-                                          const PrimMask* mask = nullptr) {
-  // mask: wave-uniform candidate set (fan_cull), nullptr = every record
+                                          PrimMask mask = PrimMask::all()) {
+  // mask: wave-uniform candidate set (fan_cull), by value so that it stays in scalar registers
   if (ac != nullptr && ac->n_nodes > 0) return nearest_accel(P, nS, nP, *ac, o, d, k_out, plane_thr);
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   int k = 0;
   for (int e = nS; k < e; ++k) {
-    if (mask != nullptr && !mask->has(k)) continue;
+    if (!mask.has(k)) continue;
     double t = sphere_t(P[k], o, d);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP; k < e; ++k) {
-    if (mask != nullptr && !mask->has(k)) continue;
+    if (!mask.has(k)) continue;
     double t = plane_t(P[k], o, d, plane_thr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP + nB; k < e; ++k) {
-    if (mask != nullptr && !mask->has(k)) continue;
+    if (!mask.has(k)) continue;
     double t = box_hit<false>(P[k], o, d, nullptr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
@@ -341,7 +342,7 @@ constexpr int SEQ_WALK_CAP = 1 << 16;
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
                                               int* queries, bool seq = false, double plane_thr = HIT_EPS,
-                                              const Accel* ac = nullptr, const PrimMask* mask = nullptr) {
+                                              const Accel* ac = nullptr, PrimMask mask = PrimMask::all()) {
   double remaining = maxdist, trans = 1.0;
   const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
   for (int step = 0; step < cap; ++step) {

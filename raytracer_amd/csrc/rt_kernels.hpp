@@ -280,12 +280,11 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
     const d3 Lp = mk3(lg[0], lg[1], lg[2]);
     double T;
     // small scenes: conservative candidate set + fully-lit / umbra shortcut (rt_device.hpp, fan_cull)
-    PrimMask cmask_v; cmask_v.lo = cmask_v.hi = ~0ull;
-    const PrimMask* cmask = nullptr;
+    PrimMask cmask = PrimMask::all();
     bool shortcut = false;
     if (sc.n <= 128 && (ac == nullptr || ac->n_nodes == 0)) {
       const FanCull fc = fan_cull(sc, P, p, Lp, n_sh > 1 ? 0.7072f * (float)lg[8] : 0.0f);
-      cmask_v = fc.act; cmask = &cmask_v;
+      cmask = fc.act;
       if (!__any(fc.lane_can & !fc.lane_full)) {
         shortcut = true;
         T = fc.lane_full ? 0.0 : 1.0;                                              // n^2 terms of exactly 0 or 1
