@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="bracket the kernels of every k-th timed frame with HIP events (the events cost ~3 %% of a 4K frame)")
+    ap.add_argument("--prewarm", type=int, default=16, help="untimed setup frames before the warmup steps (workspace growth, clock ramp)")
     ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with a full-frame render on rank 0")
     args = ap.parse_args()
 
@@ -195,6 +196,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # setup: a few frames so that the library has grown its workspace and the GPU is at its sustained
+    # clocks (kernel times settle after ~6 back-to-back frames, tools/frame_times.py), then the W warmup steps
+    for _ in range(max(0, args.prewarm)):       # a fixed count: every rank must issue the same collectives
+        step(_lib.Stats())
+    for sc_ in scenes:
+        sc_.sync()
     for _ in range(args.warmup):
         step(_lib.Stats())
     for sc_ in scenes:
