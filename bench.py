@@ -51,15 +51,15 @@ def load_workload(name):
 
 
 def cpu_baseline(name, gs, cam, st, mats, surfs, lights, W, H, precision):
-    """Time the oracle on a bounded sample (a quarter-resolution frame of the same workload) and
-    check the GPU render of the same sample against it."""
+    """Time the oracle on a bounded sample (a half-resolution frame of the same workload: ~30 s of CPU
+    work spread over the threads) and check the GPU render of the same sample against it."""
     import numpy as np
     from oracle import oracle
     from raytracer_amd.image import quantize_u8
     threads = min(16, os.cpu_count() or 1)
     oracle.build()
     oracle.set_threads(threads)
-    div = 4 if name != "synth4k" else 40
+    div = 2 if name != "synth4k" else 40
     w, h = max(W // div, 16), max(H // div, 9)
     cam.setup(w / h)
     t0 = time.perf_counter()
