@@ -717,6 +717,8 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   FrameParams fp;
   fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
   fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
+  // 8x8 pixel tiles per wave at level 0; the numpy-stream mode needs hits in ascending pixel order
+  fp.rs.tiled = (fr->jitter_mode == RT_JITTER_PIXEL_KEYED && !getenv("RT_NO_TILES")) ? 1 : 0; fp.rs.pad = 0;
   fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)s->cap_queue;
   fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
   fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;

@@ -453,7 +453,7 @@ __device__ __forceinline__ d3 camera_dir(const DevCamera& c, int W, int H, int x
 }
 
 // Row sets (include/rt_hip.h, rt_frame): local row -> global row.
-struct RowSet { int32_t W, H, block_rows, part, n_parts, rows; };
+struct RowSet { int32_t W, H, block_rows, part, n_parts, rows; int32_t tiled, pad; };   // tiled: level-0 slots walk 8x8 pixel tiles
 __host__ __device__ __forceinline__ int rowset_global_y(const RowSet& rs, int local_row) {
   if (rs.n_parts <= 1) return local_row;
   int b = local_row / rs.block_rows, r = local_row - b * rs.block_rows;

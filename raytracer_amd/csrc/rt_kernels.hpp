@@ -119,16 +119,38 @@ __device__ __forceinline__ void fb_put(FB* fb, bool first, uint32_t lp, double r
   }
 }
 
+// Level-0 slot -> local pixel index.  With rs.tiled the slots walk 8x8 pixel tiles (a wave = one tile,
+// a 1024-ray trace chunk = a 128x8 strip) instead of 64x1 row segments: the hits of a wave are then
+// spatially compact, so fewer waves straddle a shadow boundary and the per-wave candidate sets of the
+// shade kernels are smaller.  Pixels outside the largest (multiple of 8) x (multiple of 8) region follow
+// in row-major order: first the right strip, then the bottom rows.  A bijection on [0, rows*W).
+__device__ __forceinline__ uint32_t level0_pixel(const RowSet& rs, uint32_t slot) {
+  if (!rs.tiled) return slot;
+  const uint32_t W = (uint32_t)rs.W, R = (uint32_t)rs.rows, W8 = W & ~7u, R8 = R & ~7u;
+  const uint32_t n_tiled = W8 * R8;
+  if (slot < n_tiled) {
+    const uint32_t tile = slot >> 6, in = slot & 63u, tpr = W8 >> 3;
+    const uint32_t ty = tile / tpr, tx = tile - ty * tpr;
+    return (ty * 8u + (in >> 3)) * W + tx * 8u + (in & 7u);
+  }
+  uint32_t s = slot - n_tiled;
+  const uint32_t wr = W - W8;                 // right strip: R8 rows x wr columns
+  if (s < R8 * wr) { const uint32_t y = s / wr; return y * W + W8 + (s - y * wr); }
+  s -= R8 * wr;                               // bottom rows: (R - R8) x W
+  return R8 * W + s;
+}
+
 struct RayIn { d3 o, d, w; uint32_t lp; };
 
 __device__ __forceinline__ RayIn load_ray(int level, uint32_t slot, const DevCamera& cam, const RowSet& rs, const RayQueue& q) {
   RayIn r;
   if (level == 0) {
+    slot = level0_pixel(rs, slot);
     uint32_t lr = slot / (uint32_t)rs.W, x = slot - lr * (uint32_t)rs.W;
     r.o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
     r.d = camera_dir(cam, rs.W, rs.H, (int)x, rowset_global_y(rs, (int)lr));
     r.w = mk3(1.0, 1.0, 1.0);
-    r.lp = slot;
+    r.lp = slot;          // (the mapped pixel)
   } else {
     r.o = mk3(q.ox[slot], q.oy[slot], q.oz[slot]);
     r.d = mk3(q.dx[slot], q.dy[slot], q.dz[slot]);
