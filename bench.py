@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pool4k", choices=sorted(WORKLOADS))
     ap.add_argument("--block-rows", type=int, default=0,
-                    help="rows per interleaved block (0 = largest value <= 16 that gives every rank the same number of rows, else 16)")
+                    help="rows per interleaved block (0 = 8, the height of the kernels' pixel tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -136,8 +136,7 @@ def main():
 
     cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
     if args.block_rows <= 0:
-        even = [b for b in range(16, 3, -1) if H % b == 0 and (H // b) % world == 0]
-        args.block_rows = even[0] if even else 16
+        args.block_rows = 8       # = the height of the kernels' 8x8 pixel tiles; rank loads differ by <= 8 rows
     n_shadow, max_depth = int(st.root_number_shadow_rays), int(st.max_recursions)
     cam.setup(W / H)
     packed = pack_scene(mats, surfs, lights, st.background_color)

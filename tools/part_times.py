@@ -16,7 +16,7 @@ buf = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(buf), W * H * 12) == 
 with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as gs:
     base = None
     for n in (1, 2, 4, 8):
-        br = [b for b in range(16, 3, -1) if H % b == 0 and (H // b) % n == 0][0]
+        br = int(os.environ.get("BR", 0)) or [b for b in range(16, 3, -1) if H % b == 0 and (H // b) % n == 0][0]
         for part in sorted({0, n - 1}):
             for _ in range(3):
                 gs.render(cam, W, H, n_sh, depth, precision=precision, jitter=1234, block_rows=br, part=part, n_parts=n,
@@ -45,7 +45,7 @@ with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as gs:
 buf2 = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(buf2), W * H * 12) == 0
 with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as a, GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as b:
     for n in (1, 2, 4, 8):
-        br = [x for x in range(16, 3, -1) if H % x == 0 and (H // x) % n == 0][0]
+        br = int(os.environ.get("BR", 0)) or [x for x in range(16, 3, -1) if H % x == 0 and (H // x) % n == 0][0]
         def go(frames):
             for k in range(frames):
                 (a if k % 2 == 0 else b).render(cam, W, H, n_sh, depth, precision=precision, jitter=1234, block_rows=br, part=0, n_parts=n,
