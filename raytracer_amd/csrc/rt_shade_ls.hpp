@@ -363,6 +363,44 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     const float ks0 = (float)mat[3], ks1 = (float)mat[4], ks2 = (float)mat[5];
     const float shin = (float)mat[9];
 
+    // ----------------------------------- wave-level pre-cull of (light, sphere) pairs ----------
+    // A wave's hits are spatially compact (8x8 pixel tile, or neighbours in the queue).  Bound them by a
+    // ball (c, rho); every shadow segment of the wave to light L lies in the hull from that ball to the
+    // ball (Lp, RL).  Lane j tests pair j = (light, sphere) against that hull ONCE per wave; for the pairs
+    // that fail, the per-lane coefficient / culling arithmetic below (~45 instructions per sphere) is skipped
+    // by wave-uniform branches.  Conservative: a pair is only dropped when no lane's fan can touch it.
+    unsigned long long pair_can = ~0ull;
+    if (nS * sc.nL <= 64) {
+      float cnt = active ? 1.0f : 0.0f, sx = active ? pf.x : 0.0f, sy = active ? pf.y : 0.0f, sz = active ? pf.z : 0.0f;
+#pragma unroll
+      for (int o_ = 32; o_ > 0; o_ >>= 1) {
+        cnt += __shfl_xor(cnt, o_); sx += __shfl_xor(sx, o_); sy += __shfl_xor(sy, o_); sz += __shfl_xor(sz, o_);
+      }
+      const float ic = 1.0f / fmaxf(cnt, 1.0f);
+      const f3 cw = mkf(sx * ic, sy * ic, sz * ic);
+      const f3 dw = mkf(pf.x - cw.x, pf.y - cw.y, pf.z - cw.z);
+      float r2 = active ? dotf(dw, dw) : 0.0f;
+#pragma unroll
+      for (int o_ = 32; o_ > 0; o_ >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o_));
+      const float rho = raw_sqrt(r2) * 1.0001f + 1e-5f * (1.0f + fabsf(cw.x) + fabsf(cw.y) + fabsf(cw.z));
+      bool may = false;
+      const int j = (int)lane;
+      if (j < nS * sc.nL) {
+        const int li = j / nS, k = j - li * nS;
+        const float* lg = s_lightf[li];
+        const float4 sf = s_sphf[k];
+        const float RL = (n_sh > 1 ? 0.7072f * lg[8] : 0.0f) * 1.001f;
+        const f3 tw = mkf(lg[0] - cw.x, lg[1] - cw.y, lg[2] - cw.z), ow = mkf(cw.x - sf.x, cw.y - sf.y, cw.z - sf.z);
+        const float T0w = dotf(tw, tw), Aw = dotf(ow, tw), o2 = dotf(ow, ow);
+        const float w0 = sf.w + rho, dl = RL - rho;                          // hull radius w0 + tau*dl around c + tau*tw
+        const float qa = T0w - dl * dl, qb = Aw - w0 * dl, qc = o2 - w0 * w0;
+        const float tau = fminf(fmaxf(-qb * raw_rcp(qa), 0.0f), 1.0f);
+        const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), qc);
+        may = (qa <= 0.0f) | (g <= 1e-4f * (T0w + o2 + w0 * w0 + 1.0f));
+      }
+      pair_can = __ballot(may);
+    }
+
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
     for (int li = 0; li < sc.nL; ++li) {
@@ -378,10 +416,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const float radius = lg[8];
       const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
       const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+      const uint32_t wcan = nS * sc.nL <= 64 ? (uint32_t)(pair_can >> (li * nS)) : 0xFFFFFFFFu;   // spheres this wave may touch
 #pragma unroll
       for (int k = 0; k < MAXS; ++k) {
         a_A[k] = a_B[k] = a_C[k] = 0.0f;
-        if (k < nS) {
+        if (k < nS && ((wcan >> k) & 1u)) {
           const float4 sf = s_sphf[k];
           const f3 oc = mkf(pf.x - sf.x, pf.y - sf.y, pf.z - sf.z);
           a_A[k] = dotf(oc, tl); a_B[k] = dotf(oc, right); a_C[k] = dotf(oc, up);
@@ -422,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
-          if (k < nS) {
+          if (k < nS && ((wcan >> k) & 1u)) {
             const float r = s_sphf[k].w;
             const float qb = a_A[k] - r * RL;
             const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
