@@ -1,0 +1,25 @@
+"""Build-time guard for the headline kernel: k_shade_ls<6,2,0,true> (pool.txt class, opaque) sits just
+below the 256-VGPR limit of 2 waves/SIMD; one more live register halves its occupancy and costs ~60 % of
+the frame rate (measured twice while developing).  Compiles that single instantiation (a few seconds,
+tools/one_kernel.sh) and checks the compiler's resource report."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+def test_headline_kernel_keeps_two_waves_per_simd():
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), "rt::k_shade_ls<6, 2, 0, true>", "rt_shade_ls.hpp"],
+                         capture_output=True, text=True, timeout=600).stdout
+    occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", out)
+    spill = re.search(r"VGPRs Spill: (\d+)", out)
+    vgprs = re.search(r" VGPRs: (\d+)", out)
+    assert occ and vgprs, out
+    assert int(occ.group(1)) >= 2, out
+    assert spill is None or int(spill.group(1)) == 0, out
+    assert int(vgprs.group(1)) <= 256
