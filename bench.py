@@ -252,10 +252,19 @@ def main():
         if shade_ms > 0:
             achieved = flops_frame / (shade_ms * 1e-3) / 1e12
             traffic = None
+            executed = None      # counted flops of the same launches from the committed PMC pass (profiles/)
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_shade_launch")
+                    rec = json.load(open(pmc)).get(args.workload, {})
+                    traffic = rec.get("hbm_bytes_per_shade_launch")
+                    if world == 1 and rec.get("executed_fp32_flops_per_frame"):
+                        ex = rec["executed_fp32_flops_per_frame"] / (shade_ms * 1e-3) / 1e12
+                        executed = {"tflops": round(ex, 2), "frac": round(ex / PEAK_TFLOPS[precision], 4),
+                                    "valu_wave_instructions_per_frame": rec.get("valu_wave_instructions_per_frame"),
+                                    "valu_active_fraction_of_wave_cycles": rec.get("valu_active_fraction_of_wave_cycles"),
+                                    "waves_per_simd": rec.get("waves_per_simd"),
+                                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU_*_F32, packed halves uncounted)"}
                 except Exception:
                     traffic = None
             small = n_pln <= 2 and ((n_box == 0 and n_sph <= 6) or (0 < n_box <= 4 and n_sph <= 4))
@@ -263,7 +272,7 @@ def main():
                         "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d) (every query tests every surface); the kernels' "
                                       "conservative culling skips part of that work, so achieved is an effective rate",
                         "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic,
+                        "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic, "executed": executed,
                         "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
                         "launches_per_step": launches, "frames_with_events": len(timed), "shade_ms_per_step": round(shade_ms, 4),
                         "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
