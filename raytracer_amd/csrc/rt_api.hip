@@ -296,7 +296,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     HIPCHK_S(hipMemcpy(s->d_pbound, pbound.data(), pbound.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
 #undef HIPCHK_S
-  s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.pad = 0;
+  s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.lds_nodes = -1;
   s->ds.prims = s->d_prims; s->ds.mats = s->d_mats; s->ds.lights = s->d_lights;
   s->ds.nS = cnt[0]; s->ds.nP = cnt[1]; s->ds.nB = cnt[2]; s->ds.n = (int)prims.size();
   s->ds.nM = desc->n_materials; s->ds.nL = desc->n_lights;
@@ -373,9 +373,22 @@ static int drain(rt_scene* s) {
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & 2))
       fprintf(stderr, "[rt debug] shortcut audit: fully-lit claims wrong %llu, umbra claims wrong %llu, penumbra lanes %llu of %llu\n",
               (unsigned long long)c.dbg[0], (unsigned long long)c.dbg[1], (unsigned long long)c.dbg[2], (unsigned long long)c.dbg[3]);
-    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && c.dbg[0])
-      fprintf(stderr, "[rt debug] k_shade_fast hierarchy walks: %llu; per walk: %.1f nodes tested (bounds of hit leaves incl.: %.1f record bounds), %.2f records processed\n",
-              (unsigned long long)c.dbg[0], (double)c.dbg[1] / c.dbg[0], (double)c.dbg[2] / c.dbg[0], (double)c.dbg[3] / c.dbg[0]);
+    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && c.dbg[0]) {
+      const int bits = atoi(getenv("RT_DEBUG_STATS"));
+      const double n0 = (double)c.dbg[0];
+      if (bits & 2048)
+        fprintf(stderr, "[rt debug] k_shade_fast large-scene walk, share of the waves' cycles: find leaves %.3f, record bounds %.3f, sample blocks %.3f\n",
+                c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
+      else if (bits & 1024)
+        fprintf(stderr, "[rt debug] k_shade_fast large-scene walks (wave, light): %llu; wave-level steps per walk: %.1f node tests, %.1f leaves, %.2f sample blocks\n",
+                (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
+      else if (bits & 128)
+        fprintf(stderr, "[rt debug] k_shade_fast wave leaf lists (wave, light): %llu, %.3f too long, %.1f leaves on average\n",
+                (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0);
+      else
+        fprintf(stderr, "[rt debug] k_shade_fast hierarchy walks (hit, light): %llu; per walk: %.1f nodes tested (holding %.1f record bounds), %.2f records processed\n",
+                (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
+    }
     if (pf.user) {
       rt_stats st; std::memset(&st, 0, sizeof st);
       st.levels = pf.levels;

@@ -48,8 +48,28 @@ static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 struct Accel {
   const BvhNode* nodes;    // nullptr / n_nodes == 0: no hierarchy (small scenes)
   const float4* pbound;    // [n] bounding sphere of each record (planes: unused)
-  int32_t n_nodes, pad;
+  int32_t n_nodes;
+  int32_t lds_nodes;       // device side: LDS byte address of a staged copy of `nodes`, -1: none (host: -1)
 };
+
+#ifdef __HIPCC__
+// One node.  A staged hierarchy is read with LDS instructions (ds_read_b128): through the generic
+// pointer the loads would be flat ones, which queue in the vector-memory address pipeline behind the
+// scattered global loads of the walks — measured as the bottleneck of the large-scene kernels.
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ BvhNode load_node(const Accel& ac, int i) {
+  union { rt_v4f v[2]; BvhNode n; } u;
+  if (ac.lds_nodes >= 0) {
+    const __attribute__((address_space(3))) rt_v4f* q =
+        (const __attribute__((address_space(3))) rt_v4f*)(uintptr_t)(uint32_t)ac.lds_nodes + 2 * i;
+    u.v[0] = q[0]; u.v[1] = q[1];
+  } else {
+    const rt_v4f* q = reinterpret_cast<const rt_v4f*>(ac.nodes) + 2 * i;
+    u.v[0] = q[0]; u.v[1] = q[1];
+  }
+  return u.n;
+}
+#endif
 
 struct DevScene {
   const Prim* prims;      // device memory, type-sorted
@@ -237,38 +257,83 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
 // latency-bound (every step depends on a load), so the successor of a hit node is fetched
 // speculatively while the node is being tested and the <= 8 record bounds of a leaf are fetched
 // together before any of them is tested.
-template <class NodeHit, class PrimMay, class OnPrim>
+// One leaf: its <= 8 record bounds are fetched together, tested, and the survivors handed to on_prim.
+template <int HALF = 8, class PrimMay, class OnPrim>
+__device__ __forceinline__ void bvh_leaf(const Accel& ac, const BvhNode& nd, PrimMay prim_may, OnPrim on_prim,
+                                         uint32_t dbg_skip = 0) {
+  const int nj = (dbg_skip & 16u) ? 0 : nd.count();
+  if (nj <= 0) return;
+  uint32_t cand = 0;
+#pragma unroll
+  for (int h = 0; h < 8; h += HALF) {        // HALF = 4: two rounds of 4 bounds (16 registers less in flight)
+    if (h > 0 && nj <= h) break;
+    float4 b[HALF];
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) b[j] = ac.pbound[nd.first + (h + j < nj ? h + j : 0)];
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) cand |= (h + j < nj && prim_may(b[j])) ? (1u << (h + j)) : 0u;
+  }
+  if (dbg_skip & 32u) cand = 0;
+  while (cand) {
+    const int j = __ffs((int)cand) - 1;
+    cand &= cand - 1;
+    on_prim(nd.first + j);
+  }
+}
+
+template <int HALF = 8, class NodeHit, class PrimMay, class OnPrim>
 __device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, PrimMay prim_may, OnPrim on_prim,
                                          uint32_t dbg_skip = 0) {
   const int n = ac.n_nodes;
   if (n <= 0) return;
   int i = 0;
-  BvhNode nd = ac.nodes[0];
+  BvhNode nd = load_node(ac, 0);
   while (i < n) {
     const int nxt = i + 1;
-    const BvhNode nx = ac.nodes[nxt < n ? nxt : i];
+    const BvhNode nx = load_node(ac, nxt < n ? nxt : i);
     if (node_hit(nd)) {
-      const int nj = (dbg_skip & 16u) ? 0 : nd.count();
-      if (nj > 0) {
-        float4 b[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = ac.pbound[nd.first + (j < nj ? j : 0)];
-        uint32_t cand = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cand |= (j < nj && prim_may(b[j])) ? (1u << j) : 0u;
-        if (dbg_skip & 32u) cand = 0;
-        while (cand) {
-          const int j = __ffs((int)cand) - 1;
-          cand &= cand - 1;
-          on_prim(nd.first + j);
-        }
-      }
+      bvh_leaf<HALF>(ac, nd, prim_may, on_prim, dbg_skip);
       i = nxt; nd = nx;
     } else {
       i = nd.skip();
-      if (i < n) nd = ac.nodes[i];
+      if (i < n) nd = load_node(ac, i);
     }
   }
+}
+
+// Wave-cooperative scan of the hierarchy: the 64 lanes test 64 consecutive nodes (depth-first order)
+// per round against ONE wave-uniform query (wave_node_hit), the leaves that pass are appended to a
+// per-wave list in LDS.  A missed inner node lets the scan jump to its skip link once the round is
+// over (descendants inside the same round are tested needlessly, which is harmless).  Returns the
+// number of leaves, or -1 when more than `cap` passed (the caller then walks per lane).  All 64
+// lanes must call this together.
+template <class WaveNodeHit>
+__device__ __forceinline__ int bvh_wave_leaves(const Accel& ac, WaveNodeHit wave_node_hit, int* __restrict__ list, int cap) {
+  const int n = ac.n_nodes;
+  const int lane = (int)__lane_id();
+  int n_list = 0;
+  for (int r0 = 0; r0 < n;) {
+    const int i = r0 + lane;
+    bool leaf_hit = false; int jump = 0;
+    if (i < n) {
+      const BvhNode nd = load_node(ac, i);
+      const bool hit = wave_node_hit(nd);
+      leaf_hit = hit & (nd.count() > 0);
+      jump = hit ? 0 : nd.skip();
+    }
+    const unsigned long long m = __ballot(leaf_hit);
+    const int cnt = __popcll(m);
+    if (n_list + cnt > cap) return -1;
+    if (leaf_hit) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
+    n_list += cnt;
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) jump = max(jump, __shfl_xor(jump, o_));
+    r0 = max(r0 + 64, jump);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return n_list;
 }
 
 // Does the ray (origin of, UNIT direction uf, fp32 copies) possibly touch the sphere (c, r) at a

@@ -84,6 +84,7 @@ constexpr int LDS_NODES = 1024;
 template <bool LDS_SCENE>
 __device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   Accel a = sc.ac;
+  a.lds_nodes = -1;
   if (LDS_SCENE) { a.n_nodes = 0; return a; }
   if (a.n_nodes <= 0 || a.n_nodes > LDS_NODES) return a;
   const int words = a.n_nodes * (int)(sizeof(BvhNode) / 16);
@@ -92,6 +93,7 @@ __device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
   __syncthreads();
   a.nodes = lds;
+  a.lds_nodes = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) BvhNode*)lds;
   return a;
 }
 

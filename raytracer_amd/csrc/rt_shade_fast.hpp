@@ -44,30 +44,47 @@ __device__ __forceinline__ f3 normalize_clamped(f3 a) {   // v / max(|v|, 1e-6)
 
 constexpr float T_LO = 2e-6f;   // see header: 1e-6 origin shift + 1e-6 hit threshold
 
+constexpr int LEAF_LIST = 20, CAND_LIST = 16;   // per-lane lists of the large-scene walk (entries, in LDS)
+constexpr int WAVE_LEAF_CAP = 64;     // leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves
+
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCENE && CH <= 9) ? 2 : 1))) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                       float* __restrict__ fb, int n_chunks) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
   __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
+  __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];
+  __shared__ uint32_t s_leaf[LDS_SCENE ? 1 : LEAF_LIST * BLOCK], s_cand[LDS_SCENE ? 1 : CAND_LIST * BLOCK];
+  int* const wl = s_wleaves + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_LEAF_CAP);
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
+  float scene_m = 0.0f;            // L1 size of the hierarchy's root box: scales the fp32 slack of the node tests
+  if (!LDS_SCENE && ac.n_nodes > 0) {
+    const BvhNode root = load_node(ac, 0);
+    scene_m = fmaxf(fabsf(root.lo[0]), fabsf(root.hi[0])) + fmaxf(fabsf(root.lo[1]), fabsf(root.hi[1])) +
+              fmaxf(fabsf(root.lo[2]), fabsf(root.hi[2]));
+  }
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t lane = __lane_id();
   const int n_sh = fp.n_shadow;
   const int n_cells = n_sh > 1 ? n_sh * n_sh : 1;
   const float inv_cells = 1.0f / (float)n_cells;
+  const long long ck_kernel = (RT_DBG(fp) & 2048u) ? clock64() : 0;
   for (;;) {
     uint32_t base = grab64(&C->work_shade[level]);
-    if (base >= count) break;
+    if (base >= count) {
+      if ((RT_DBG(fp) & 2048u) && lane == 0) atomicAdd(&C->dbg[0], (unsigned long long)(clock64() - ck_kernel));
+      break;
+    }
     uint32_t h = base + lane;
     bool active = h < count;
     RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0);
     const double* mat = sc.mats;
     r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
-    if (active) {
-      HitRec hr = hits[h];
+    {   // the idle lanes of a level's last wave shade a copy of its last hit (results dropped): the
+        // wave-level steps below need all 64 lanes
+      HitRec hr = hits[active ? h : count - 1];
       r = load_ray(level, hr.slot, cam, fp.rs, q);
       const Prim& pr = P[hr.prim];
       const double t = hr.t;
@@ -79,6 +96,26 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
       const uint32_t gpix = global_pixel(fp.rs, r.lp);
       const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);
       float dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+      // Large scene: ball (cw, rho) around the wave's hits.  A wave's hits are compact (8x8 pixel tile, or
+      // neighbours in the queue), so the hierarchy is first scanned ONCE per (wave, light) with the hull
+      // of all its shadow fans (bvh_wave_leaves); the lanes then test only the leaves that survive.
+      const bool coop = !LDS_SCENE && ac.n_nodes > 0 && !(RT_DBG(fp) & 64u);
+      f3 cw = mkf(0, 0, 0); float rho = 0.0f;
+      if (coop) {
+        const f3 pf = tof(p);
+        f3 lo = pf, hi = pf;
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) {
+          lo.x = fminf(lo.x, __shfl_xor(lo.x, o_)); lo.y = fminf(lo.y, __shfl_xor(lo.y, o_)); lo.z = fminf(lo.z, __shfl_xor(lo.z, o_));
+          hi.x = fmaxf(hi.x, __shfl_xor(hi.x, o_)); hi.y = fmaxf(hi.y, __shfl_xor(hi.y, o_)); hi.z = fmaxf(hi.z, __shfl_xor(hi.z, o_));
+        }
+        cw = mkf(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+        const f3 dw = mkf(pf.x - cw.x, pf.y - cw.y, pf.z - cw.z);
+        float r2 = dotf(dw, dw);
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o_));
+        rho = raw_sqrt(r2) * 1.0001f;
+      }
       for (int li = 0; li < sc.nL; ++li) {
         const double* lg = sc.lights + LIGHT_STRIDE * li;
         const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
@@ -103,9 +140,42 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
           skip_samples = !(RT_DBG(fp) & 2u) && !__any(fc.lane_can & !fc.lane_full);
         }
         if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
+        int n_wl = -1;
+        if (coop) {
+          // segment cw -> Lp against the node box grown by max(rho, RL) (+ fp32 slack), 0 <= tau <= 1
+          const f3 tw = mkf((float)lg[0] - cw.x, (float)lg[1] - cw.y, (float)lg[2] - cw.z);
+          const float RLw = n_sh > 1 ? 0.7072f * radius * 1.001f : 0.0f;
+          const float gs = 4e-5f * (1.0f + fabsf(tw.x) + fabsf(tw.y) + fabsf(tw.z) + fabsf(cw.x) + fabsf(cw.y) + fabsf(cw.z));
+          const float gw = fmaxf(rho, RLw) + gs;
+          const float hx = fabsf(tw.x) > 1e-20f ? raw_rcp(tw.x) : 1e30f, hy = fabsf(tw.y) > 1e-20f ? raw_rcp(tw.y) : 1e30f,
+                      hz = fabsf(tw.z) > 1e-20f ? raw_rcp(tw.z) : 1e30f;
+          n_wl = bvh_wave_leaves(ac, [&](const BvhNode& nd) __attribute__((always_inline)) {
+            const float ax = (nd.lo[0] - gw - cw.x) * hx, bx = (nd.hi[0] + gw - cw.x) * hx;
+            const float ay = (nd.lo[1] - gw - cw.y) * hy, by = (nd.hi[1] + gw - cw.y) * hy;
+            const float az = (nd.lo[2] - gw - cw.z) * hz, bz = (nd.hi[2] + gw - cw.z) * hz;
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), 1.0f));
+            if (!(tn <= tf + 1e-5f)) return false;
+            // the hull's radius at parameter tau is rho + tau*(RLw - rho) and tau <= tf inside this box: when
+            // the light end is the wide one, test again with the radius reached at tf
+            const float g2 = fmaxf(rho, fmaf(tf + 1e-5f, RLw - rho, rho)) + gs;
+            const float ax2 = (nd.lo[0] - g2 - cw.x) * hx, bx2 = (nd.hi[0] + g2 - cw.x) * hx;
+            const float ay2 = (nd.lo[1] - g2 - cw.y) * hy, by2 = (nd.hi[1] + g2 - cw.y) * hy;
+            const float az2 = (nd.lo[2] - g2 - cw.z) * hz, bz2 = (nd.hi[2] + g2 - cw.z) * hz;
+            const float tn2 = fmaxf(fmaxf(fminf(ax2, bx2), fminf(ay2, by2)), fmaxf(fminf(az2, bz2), 0.0f));
+            const float tf2 = fminf(fminf(fmaxf(ax2, bx2), fmaxf(ay2, by2)), fminf(fmaxf(az2, bz2), 1.0f));
+            return tn2 <= tf2 + 1e-5f;
+          }, wl, WAVE_LEAF_CAP);
+          if ((RT_DBG(fp) & 128u) && lane == 0) {
+            atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], n_wl < 0 ? 1ull : 0ull); atomicAdd(&C->dbg[2], (unsigned long long)(n_wl < 0 ? 0 : n_wl));
+          }
+        }
         for (int c = 0; c < (skip_samples ? 0 : n_chunks); ++c) {
           float dx[CH], dy[CH], dz[CH], md[CH], tr[CH];
-          float ix[HAS_BOX ? CH : 1], iy[HAS_BOX ? CH : 1], iz[HAS_BOX ? CH : 1];
+          // inverse directions for the box slabs: kept per sample for LDS scenes; the large-scene kernel
+          // recomputes them per (box, sample) instead — boxes are few after culling, registers are not
+          constexpr bool KEEP_INV = HAS_BOX && LDS_SCENE;
+          float ix[KEEP_INV ? CH : 1], iy[KEEP_INV ? CH : 1], iz[KEEP_INV ? CH : 1];
 #pragma unroll
           for (int s = 0; s < CH; ++s) {
             const int cellidx = c * CH + s;
@@ -122,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             dx[s] = ts.x * rinv; dy[s] = ts.y * rinv; dz[s] = ts.z * rinv;
             md[s] = d2 * rinv;
             tr[s] = (cellidx < n_cells) ? 1.0f : 0.0f;
-            if (HAS_BOX) { ix[s] = raw_rcp(dx[s]); iy[s] = raw_rcp(dy[s]); iz[s] = raw_rcp(dz[s]); }
+            if (KEEP_INV) { ix[s] = raw_rcp(dx[s]); iy[s] = raw_rcp(dy[s]); iz[s] = raw_rcp(dz[s]); }
           }
           // per-primitive blocks: everything that depends on (hit, primitive) once, then CH samples
           auto do_sphere = [&](const Prim& s_) __attribute__((always_inline)) {   // sphere.py:49-71
@@ -150,9 +220,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
-              const float ax = lo.x * ix[HAS_BOX ? s : 0], bx = hi.x * ix[HAS_BOX ? s : 0];
-              const float ay = lo.y * iy[HAS_BOX ? s : 0], by = hi.y * iy[HAS_BOX ? s : 0];
-              const float az = lo.z * iz[HAS_BOX ? s : 0], bz = hi.z * iz[HAS_BOX ? s : 0];
+              const float jx = KEEP_INV ? ix[KEEP_INV ? s : 0] : raw_rcp(dx[s]), jy = KEEP_INV ? iy[KEEP_INV ? s : 0] : raw_rcp(dy[s]),
+                          jz = KEEP_INV ? iz[KEEP_INV ? s : 0] : raw_rcp(dz[s]);
+              const float ax = lo.x * jx, bx = hi.x * jx;
+              const float ay = lo.y * jy, by = hi.y * jy;
+              const float az = lo.z * jz, bz = hi.z * jz;
               const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
               const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
               const bool ok = tn <= tf;
@@ -182,41 +254,133 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
             // to this light (all samples lie within RL of the light centre) and runs the sample block
             // only for the spheres / boxes that can cross one of them.  Results are those of the
             // brute-force loops below (the skipped primitives contribute a factor of exactly 1).
+            // All of it is parametrised from the LIGHT end (y(s) = Lp + s*(p - Lp), fan radius RL*(1 - s)):
+            // a reflected ray can hit the floor 1e6 units away, and from that end every product and sum
+            // near the scene would carry the rounding of 1e6-sized coordinates (bounds would have to be
+            // inflated by tens of units: such a hit made every record a candidate).  From the light end
+            // the far point only enters through s*d with s ~ 1e-4.
             const float RL = n_sh > 1 ? 0.7072f * radius * 1.001f : 0.0f;
             const float qa = dotf(tl, tl) - RL * RL, rqa = raw_rcp(qa);
-            const float pfx = (float)p.x, pfy = (float)p.y, pfz = (float)p.z;
-            const float e1 = fabsf(tl.x) + fabsf(tl.y) + fabsf(tl.z);
+            const float Lx = (float)lg[0], Ly = (float)lg[1], Lz = (float)lg[2];
+            const float ddx = -tl.x, ddy = -tl.y, ddz = -tl.z;                      // p - Lp
             auto fan_may_touch = [&](float cx, float cy, float cz, float r) __attribute__((always_inline)) {
-              const float ux = pfx - cx, uy = pfy - cy, uz = pfz - cz;
-              const float rs = r + 4e-5f * (1.0f + e1 + fabsf(ux) + fabsf(uy) + fabsf(uz));
-              const float qb = fmaf(uz, tl.z, fmaf(uy, tl.y, ux * tl.x)) - rs * RL;
-              const float ta = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
-              const float xx = fmaf(ta, tl.x, ux), xy = fmaf(ta, tl.y, uy), xz = fmaf(ta, tl.z, uz);
-              const float w = fmaf(ta, RL, rs);
-              return (qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= w * w);
+              const float wx = Lx - cx, wy = Ly - cy, wz = Lz - cz;
+              const float R0 = r + RL + 4e-5f * (1.0f + fabsf(wx) + fabsf(wy) + fabsf(wz));
+              const float qb = fmaf(wz, ddz, fmaf(wy, ddy, wx * ddx)) + RL * R0;
+              const float sa = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);                // min of |w + s d|^2 - (R0 - s RL)^2
+              const float xx = fmaf(sa, ddx, wx), xy = fmaf(sa, ddy, wy), xz = fmaf(sa, ddz, wz);
+              const float wr = fmaf(-sa, RL, R0);
+              return (qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= wr * wr);
             };
-            // node boxes: segment p -> Lp against the box grown by RL (+ fp32 slack), 0 <= tau <= 1
-            const float gx = fabsf(tl.x) > 1e-20f ? raw_rcp(tl.x) : 1e30f, gy = fabsf(tl.y) > 1e-20f ? raw_rcp(tl.y) : 1e30f,
-                        gz = fabsf(tl.z) > 1e-20f ? raw_rcp(tl.z) : 1e30f;
-            const float grow = RL + 4e-5f * (1.0f + e1 + fabsf(pfx) + fabsf(pfy) + fabsf(pfz));
+            // node boxes: segment Lp -> p against the box grown by the fan radius (+ fp32 slack), 0 <= s <= 1
+            const float gx = fabsf(ddx) > 1e-20f ? raw_rcp(ddx) : 1e30f, gy = fabsf(ddy) > 1e-20f ? raw_rcp(ddy) : 1e30f,
+                        gz = fabsf(ddz) > 1e-20f ? raw_rcp(ddz) : 1e30f;
+            const float nslack = 4e-5f * (1.0f + fabsf(Lx) + fabsf(Ly) + fabsf(Lz) + scene_m);
+            const float grow = RL + nslack;
             unsigned dbg_nodes = 0, dbg_bounds = 0, dbg_cands = 0;
-            bvh_walk(ac,
-              [&](const BvhNode& nd) __attribute__((always_inline)) {
-                if (RT_DBG(fp)) { ++dbg_nodes; dbg_bounds += nd.count(); }
-                const float ax = (nd.lo[0] - grow - pfx) * gx, bx = (nd.hi[0] + grow - pfx) * gx;
-                const float ay = (nd.lo[1] - grow - pfy) * gy, by = (nd.hi[1] + grow - pfy) * gy;
-                const float az = (nd.lo[2] - grow - pfz) * gz, bz = (nd.hi[2] + grow - pfz) * gz;
-                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), 1.0f));
-                return tn <= tf + 1e-5f;
-              },
-              [&](const float4& b) __attribute__((always_inline)) { return fan_may_touch(b.x, b.y, b.z, b.w); },
-              [&](int k) __attribute__((always_inline)) {
-                if (RT_DBG(fp)) ++dbg_cands;
-                if (k < sc.nS) do_sphere(P[k]);
-                else if (HAS_BOX) do_box(P[k]);
-              }, RT_DBG(fp));
-            if (RT_DBG(fp)) {
+            auto node_hit = [&](const BvhNode& nd) __attribute__((always_inline)) {
+              if (RT_DBG(fp)) { ++dbg_nodes; dbg_bounds += nd.count(); }
+              const float ax = (nd.lo[0] - grow - Lx) * gx, bx = (nd.hi[0] + grow - Lx) * gx;
+              const float ay = (nd.lo[1] - grow - Ly) * gy, by = (nd.hi[1] + grow - Ly) * gy;
+              const float az = (nd.lo[2] - grow - Lz) * gz, bz = (nd.hi[2] + grow - Lz) * gz;
+              const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+              const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), 1.0f));
+              if (!(tn <= tf + 2e-6f)) return false;
+              if (RL == 0.0f || (RT_DBG(fp) & 256u)) return true;
+              // the fan is a cone: its radius at parameter s is (1 - s)*RL, and s >= tn inside this box.
+              // Second test with the box grown by that radius only.
+              const float g2 = fmaf(1.0f - fmaxf(tn - 2e-6f, 0.0f), RL, nslack);
+              const float ax2 = (nd.lo[0] - g2 - Lx) * gx, bx2 = (nd.hi[0] + g2 - Lx) * gx;
+              const float ay2 = (nd.lo[1] - g2 - Ly) * gy, by2 = (nd.hi[1] + g2 - Ly) * gy;
+              const float az2 = (nd.lo[2] - g2 - Lz) * gz, bz2 = (nd.hi[2] + g2 - Lz) * gz;
+              const float tn2 = fmaxf(fmaxf(fminf(ax2, bx2), fminf(ay2, by2)), fmaxf(fminf(az2, bz2), 0.0f));
+              const float tf2 = fminf(fminf(fmaxf(ax2, bx2), fmaxf(ay2, by2)), fminf(fmaxf(az2, bz2), 1.0f));
+              return tn2 <= tf2 + 2e-6f;
+            };
+            // The walk is split into three phases so that the lanes of a wave stay together (a wave pays for
+            // every branch any of its lanes takes):
+            //   1. find leaves: node tests only; each lane lists the leaves its fan may touch (LDS, per lane),
+            //      either by walking the tree or by filtering the wave's leaf list;
+            //   2. every lane takes one listed leaf per step: its <= 8 record bounds are tested together, the
+            //      records that pass go to the lane's candidate list;
+            //   3. every lane takes one candidate per step: the exact sample block.
+            // Lists are bounded: a full leaf list pauses phase 1, a nearly full candidate list pauses phase 2.
+            uint32_t* const my_leaf = s_leaf + threadIdx.x;       // entry e at [e * BLOCK]
+            uint32_t* const my_cand = s_cand + threadIdx.x;
+            const int n_nodes = ac.n_nodes;
+            const int w_end = n_wl >= 0 ? n_wl : n_nodes;
+            int wi = 0;                     // phase-1 position: wave-list entry (uniform) or node index (per lane)
+            int n_leaf = 0, le = 0, n_cand = 0;
+            unsigned it1 = 0, it2 = 0, it3 = 0;
+            long long ck1 = 0, ck2 = 0, ck3 = 0, ck0 = (RT_DBG(fp) & 2048u) ? clock64() : 0;
+            for (;;) {
+              if (!__any(le < n_leaf)) {
+                if (!__any(wi < w_end)) break;
+                n_leaf = 0; le = 0;
+                if (n_wl >= 0) {
+                  for (; wi < n_wl && !__any(n_leaf >= LEAF_LIST); ++wi) {
+                    const BvhNode nd = load_node(ac, wl[wi]);
+                    if (RT_DBG(fp)) ++it1;
+                    if (node_hit(nd)) { my_leaf[n_leaf * BLOCK] = (uint32_t)nd.first | ((uint32_t)nd.count() << 28); ++n_leaf; }
+                  }
+                } else {
+                  BvhNode nd = load_node(ac, wi < n_nodes ? wi : 0);
+                  while (wi < n_nodes && n_leaf < LEAF_LIST) {
+                    const int nxt = wi + 1;
+                    if (RT_DBG(fp)) ++it1;
+                    const BvhNode nx = load_node(ac, nxt < n_nodes ? nxt : wi);
+                    if (node_hit(nd)) {
+                      if (nd.count() > 0) { my_leaf[n_leaf * BLOCK] = (uint32_t)nd.first | ((uint32_t)nd.count() << 28); ++n_leaf; }
+                      wi = nxt; nd = nx;
+                    } else {
+                      wi = nd.skip();
+                      if (wi < n_nodes) nd = load_node(ac, wi);
+                    }
+                  }
+                }
+              }
+              if (RT_DBG(fp) & 2048u) { const long long t = clock64(); ck1 += t - ck0; ck0 = t; }
+              if (RT_DBG(fp) & 16u) n_leaf = 0;
+              while (__any(le < n_leaf) && !__any(n_cand > CAND_LIST - 8)) {
+                if (le < n_leaf) {
+                  const uint32_t packed = my_leaf[le * BLOCK];
+                  const int first = (int)(packed & 0x0FFFFFFFu), nj = (int)(packed >> 28);
+                  float4 b[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) b[j] = ac.pbound[first + (j < nj ? j : 0)];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                    if (j < nj && fan_may_touch(b[j].x, b[j].y, b[j].z, b[j].w)) { my_cand[n_cand * BLOCK] = (uint32_t)(first + j); ++n_cand; }
+                }
+                ++le;
+                if (RT_DBG(fp)) ++it2;
+              }
+              if (RT_DBG(fp) & 2048u) { const long long t = clock64(); ck2 += t - ck0; ck0 = t; }
+              if (RT_DBG(fp) & 32u) n_cand = 0;
+              for (int e = 0; __any(e < n_cand); ++e) {
+                if (RT_DBG(fp)) ++it3;
+                if (e < n_cand) {
+                  const int k = (int)my_cand[e * BLOCK];
+                  if (RT_DBG(fp)) ++dbg_cands;
+                  if (k < sc.nS) do_sphere(P[k]);
+                  else if (HAS_BOX) do_box(P[k]);
+                }
+              }
+              n_cand = 0;
+              if (RT_DBG(fp) & 2048u) { const long long t = clock64(); ck3 += t - ck0; ck0 = t; }
+            }
+            if ((RT_DBG(fp) & 2048u) && lane == 0) {       // cycles per phase, summed over waves
+              atomicAdd(&C->dbg[1], (unsigned long long)ck1);
+              atomicAdd(&C->dbg[2], (unsigned long long)ck2); atomicAdd(&C->dbg[3], (unsigned long long)ck3);
+            }
+            if (RT_DBG(fp) & 1024u) {       // wave-level step counts of the three phases
+              for (int o_ = 32; o_ > 0; o_ >>= 1) it1 = max(it1, (unsigned)__shfl_xor((int)it1, o_));
+              if (lane == 0) {
+                atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], (unsigned long long)it1);
+                atomicAdd(&C->dbg[2], (unsigned long long)it2); atomicAdd(&C->dbg[3], (unsigned long long)it3);
+              }
+            }
+            if ((RT_DBG(fp) & 1u) && active) {
               atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], (unsigned long long)dbg_nodes);
               atomicAdd(&C->dbg[2], (unsigned long long)dbg_bounds); atomicAdd(&C->dbg[3], (unsigned long long)dbg_cands);
             }
@@ -230,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
         }
-        if ((RT_DBG(fp) & 2u) && LDS_SCENE) {      // audit build, shortcut disabled: check what it would have claimed
+        if ((RT_DBG(fp) & 2u) && LDS_SCENE && active) {      // audit build, shortcut disabled: check what it would have claimed
           if (lane_lit && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
           if (lane_dark && total != 0.0f) atomicAdd(&C->dbg[1], 1ull);
           if (!lane_lit && !lane_dark) atomicAdd(&C->dbg[2], 1ull);
@@ -259,8 +423,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_fast(DevScene sc, DevCamera cam
       if (seq_background_term(fp, level, mat)) {                                            // ray_tracer.py:370-377
         bt[0] = (float)(sc.bg[0] * mat[10]); bt[1] = (float)(sc.bg[1] * mat[10]); bt[2] = (float)(sc.bg[2] * mat[10]);
       }
-      fb_put(fb, level == 0, r.lp, (float)r.w.x * ((dif[0] + spc[0]) * one_m + bt[0]),
-             (float)r.w.y * ((dif[1] + spc[1]) * one_m + bt[1]), (float)r.w.z * ((dif[2] + spc[2]) * one_m + bt[2]));
+      if (active)
+        fb_put(fb, level == 0, r.lp, (float)r.w.x * ((dif[0] + spc[0]) * one_m + bt[0]),
+               (float)r.w.y * ((dif[1] + spc[1]) * one_m + bt[1]), (float)r.w.z * ((dif[2] + spc[2]) * one_m + bt[2]));
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C);
   }
