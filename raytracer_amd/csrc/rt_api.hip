@@ -20,6 +20,7 @@
 #include "rt_shade_fast.hpp"
 #include "rt_shade_ls.hpp"
 #include "rt_stream.hpp"
+#include "rt_sort.hpp"
 #include <cmath>
 #include <hipcub/hipcub.hpp>
 
@@ -188,6 +189,9 @@ struct rt_scene {
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
   void* d_out = nullptr;         // conversion / staging target
   HitRec* d_hits = nullptr;
+  // large scenes: hits of level >= 1 are regrouped by grid cell before shading (rt_sort.hpp)
+  bool sort_hits = false; SortGrid sort_grid{};
+  HitRec* d_hits_sorted = nullptr; uint16_t* d_sort_keys = nullptr; uint32_t* d_sort_table = nullptr;
   double* d_qbuf[2] = {nullptr, nullptr};   // 9*cap_queue doubles each
   uint32_t* d_qpix[2] = {nullptr, nullptr};
   Counters* d_counters = nullptr;
@@ -201,6 +205,10 @@ static void free_workspace(rt_scene* s) {
   if (s->d_fb) hipFree(s->d_fb);
   if (s->d_out) hipFree(s->d_out);
   if (s->d_hits) hipFree(s->d_hits);
+  if (s->d_hits_sorted) hipFree(s->d_hits_sorted);
+  if (s->d_sort_keys) hipFree(s->d_sort_keys);
+  if (s->d_sort_table) hipFree(s->d_sort_table);
+  s->d_hits_sorted = nullptr; s->d_sort_keys = nullptr; s->d_sort_table = nullptr;
   for (int i = 0; i < 2; ++i) { if (s->d_qbuf[i]) hipFree(s->d_qbuf[i]); if (s->d_qpix[i]) hipFree(s->d_qpix[i]); }
   s->d_fb = s->d_out = nullptr; s->d_hits = nullptr;
   s->d_qbuf[0] = s->d_qbuf[1] = nullptr; s->d_qpix[0] = s->d_qpix[1] = nullptr;
@@ -305,6 +313,20 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
   s->ds.all_opaque = s->all_opaque ? 1 : 0; s->ds.pad = 0;
   if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
+  if (!nodes.empty() && !(getenv("RT_SORT_HITS") && atoi(getenv("RT_SORT_HITS")) == 0)) {
+    // grid over the hierarchy's root box: 12 bits, each given to the axis whose cells are largest
+    s->sort_hits = true;
+    SortGrid& g = s->sort_grid;
+    float ext[3]; int bits[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) { g.lo[k] = nodes[0].lo[k]; ext[k] = std::max(nodes[0].hi[k] - nodes[0].lo[k], 1e-20f); }
+    for (int b = 0; b < 12; ++b) {
+      int best = 0;
+      for (int k = 1; k < 3; ++k) if (std::ldexp(ext[k], -bits[k]) > std::ldexp(ext[best], -bits[best])) best = k;
+      ++bits[best];
+    }
+    for (int k = 0; k < 3; ++k) { g.n[k] = 1 << bits[k]; g.inv[k] = (float)g.n[k] / ext[k]; }
+    g.pad = 0;
+  }
   *out = s;
   return RT_OK;
 }
@@ -438,6 +460,11 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     if (q > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
     HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_hits, q * sizeof(HitRec)));
+    if (s->sort_hits) {
+      HIPCHK(hipMalloc(&s->d_hits_sorted, q * sizeof(HitRec)));
+      HIPCHK(hipMalloc(&s->d_sort_keys, q * sizeof(uint16_t)));
+      HIPCHK(hipMalloc(&s->d_sort_table, (size_t)SORT_BINS * SORT_BLOCKS * sizeof(uint32_t)));
+    }
     for (int i = 0; i < 2; ++i) {
       HIPCHK(hipMalloc(&s->d_qbuf[i], q * 9 * sizeof(double)));
       HIPCHK(hipMalloc(&s->d_qpix[i], q * sizeof(uint32_t)));
@@ -504,17 +531,27 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
       if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
       else hipLaunchKernelGGL((k_trace<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
     }
+    const HitRec* level_hits = s->d_hits;
+    if (s->sort_hits && level >= 1) {
+      Timed t(s, pf, 2);
+      hipLaunchKernelGGL(k_sort_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, cam, fp, level, cur, s->d_hits,
+                         s->d_counters, s->sort_grid, s->d_sort_keys, s->d_sort_table);
+      hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_THREADS), 0, s->stream, s->d_sort_table);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, fp, level, s->d_hits, s->d_counters,
+                         s->d_sort_keys, s->d_sort_table, s->d_hits_sorted);
+      level_hits = s->d_hits_sorted;
+    }
     {
       Timed t(s, pf, 1);
       if (fr->precision == RT_FP64) {
-        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
-        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, fb);
+        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, s->d_counters, fb);
+        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, s->d_counters, fb);
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, s->d_counters, (float*)fb, sgrid, s->stream);
         if (!done)
-          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, s->d_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, s->d_counters, (float*)fb, sgrid, s->stream);
       }
     }
   }

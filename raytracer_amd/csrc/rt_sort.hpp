@@ -1,0 +1,101 @@
+// Spatial regrouping of a bounce level's hit list (large scenes only).
+//
+// The hits of level >= 1 arrive in the order of their parent rays: one wave's 64 hits are spread
+// over the scene, so its lanes walk different parts of the culling hierarchy (every wave-level
+// step is paid for the slowest lane, node and bound loads do not coalesce) and the wave-level leaf
+// list of k_shade_fast overflows.  A counting sort by the grid cell of the hit point makes waves
+// compact again; the children they spawn inherit the order, which helps the next level's k_trace.
+// The shaded values do not depend on the order (jitter is keyed by pixel/level/light, framebuffer
+// updates are atomic adds), so this is a pure scheduling step — it has no counterpart in the
+// reference, whose batches are NumPy arrays in parent order (ray_tracer.py:491-515).
+//
+// Three launches, no global atomics: per-block histograms in LDS -> table[bin][block], one-block
+// exclusive scan of the table (bin-major = final order), scatter with LDS cursors.
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+constexpr int SORT_BINS = 4096;       // grid cells (12 bits split over the axes by the host)
+constexpr int SORT_BLOCKS = 128;      // blocks of the count / scatter launches; block b owns one contiguous range
+constexpr int SORT_THREADS = 1024;
+
+struct SortGrid {                     // cell of p: clamp((p - lo) * inv, 0, n - 1) per axis, index (x * ny + y) * nz + z
+  float lo[3], inv[3];
+  int32_t n[3];
+  int32_t pad;
+};
+
+__device__ __forceinline__ void sort_range(const Counters* C, const FrameParams& fp, int level, uint32_t* begin, uint32_t* end) {
+  uint32_t count = C->n_hits[level];
+  if (count > fp.queue_cap) count = fp.queue_cap;
+  const uint32_t chunk = (count + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  const uint32_t b = blockIdx.x * chunk;
+  *begin = b < count ? b : count;
+  *end = b + chunk < count ? b + chunk : count;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                             const HitRec* __restrict__ hits, const Counters* C, SortGrid g,
+                                                             uint16_t* __restrict__ keys, uint32_t* __restrict__ table) {
+  __shared__ uint32_t s_hist[SORT_BINS];
+  for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) s_hist[b] = 0u;
+  __syncthreads();
+  uint32_t begin, end;
+  sort_range(C, fp, level, &begin, &end);
+  for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
+    const HitRec hr = hits[i];
+    const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
+    const float px = (float)(r.o.x + hr.t * r.d.x), py = (float)(r.o.y + hr.t * r.d.y), pz = (float)(r.o.z + hr.t * r.d.z);
+    // (NaN / inf -> cell 0 or the last one: fminf/fmaxf drop NaNs, the conversion saturates)
+    const int cx = (int)fminf(fmaxf((px - g.lo[0]) * g.inv[0], 0.0f), (float)(g.n[0] - 1));
+    const int cy = (int)fminf(fmaxf((py - g.lo[1]) * g.inv[1], 0.0f), (float)(g.n[1] - 1));
+    const int cz = (int)fminf(fmaxf((pz - g.lo[2]) * g.inv[2], 0.0f), (float)(g.n[2] - 1));
+    const uint32_t key = (uint32_t)((cx * g.n[1] + cy) * g.n[2] + cz);
+    keys[i] = (uint16_t)key;
+    atomicAdd(&s_hist[key], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) table[(size_t)b * SORT_BLOCKS + blockIdx.x] = s_hist[b];
+}
+
+// Exclusive scan of table[SORT_BINS * SORT_BLOCKS] in place (one block; 2 MiB, L2-resident).
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(uint32_t* __restrict__ table) {
+  constexpr int PER = SORT_BINS * SORT_BLOCKS / SORT_THREADS;      // consecutive entries per thread
+  static_assert(PER % 4 == 0, "scan reads uint4");
+  __shared__ uint32_t s_sum[SORT_THREADS];
+  uint4* mine = reinterpret_cast<uint4*>(table + (size_t)threadIdx.x * PER);
+  uint32_t sum = 0;
+  for (int i = 0; i < PER / 4; ++i) { const uint4 v = mine[i]; sum += (v.x + v.y) + (v.z + v.w); }
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < SORT_THREADS; o <<= 1) {                      // Hillis-Steele inclusive scan of the sums
+    const uint32_t add = threadIdx.x >= (unsigned)o ? s_sum[threadIdx.x - o] : 0u;
+    __syncthreads();
+    s_sum[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[threadIdx.x] - sum;
+  for (int i = 0; i < PER / 4; ++i) {
+    const uint4 v = mine[i];
+    uint4 o;
+    o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
+    mine[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(FrameParams fp, int level, const HitRec* __restrict__ hits,
+                                                               const Counters* C, const uint16_t* __restrict__ keys,
+                                                               const uint32_t* __restrict__ table, HitRec* __restrict__ out) {
+  __shared__ uint32_t s_cur[SORT_BINS];
+  for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) s_cur[b] = table[(size_t)b * SORT_BLOCKS + blockIdx.x];
+  __syncthreads();
+  uint32_t begin, end;
+  sort_range(C, fp, level, &begin, &end);
+  for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
+    const uint32_t pos = atomicAdd(&s_cur[keys[i]], 1u);
+    out[pos] = hits[i];
+  }
+}
+
+}  // namespace rt
