@@ -316,16 +316,18 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (!nodes.empty() && !(getenv("RT_SORT_HITS") && atoi(getenv("RT_SORT_HITS")) == 0)) {
     // grid over the hierarchy's root box: 12 bits, each given to the axis whose cells are largest
     s->sort_hits = true;
-    SortGrid& g = s->sort_grid;
-    float ext[3]; int bits[3] = {0, 0, 0};
-    for (int k = 0; k < 3; ++k) { g.lo[k] = nodes[0].lo[k]; ext[k] = std::max(nodes[0].hi[k] - nodes[0].lo[k], 1e-20f); }
-    for (int b = 0; b < 12; ++b) {
-      int best = 0;
-      for (int k = 1; k < 3; ++k) if (std::ldexp(ext[k], -bits[k]) > std::ldexp(ext[best], -bits[best])) best = k;
-      ++bits[best];
-    }
-    for (int k = 0; k < 3; ++k) { g.n[k] = 1 << bits[k]; g.inv[k] = (float)g.n[k] / ext[k]; }
-    g.pad = 0;
+    auto make_grid = [&](SortGrid& g, int total_bits) {
+      float ext[3]; int bits[3] = {0, 0, 0};
+      for (int k = 0; k < 3; ++k) { g.lo[k] = nodes[0].lo[k]; ext[k] = std::max(nodes[0].hi[k] - nodes[0].lo[k], 1e-20f); }
+      for (int b = 0; b < total_bits; ++b) {
+        int best = 0;
+        for (int k = 1; k < 3; ++k) if (std::ldexp(ext[k], -bits[k]) > std::ldexp(ext[best], -bits[best])) best = k;
+        ++bits[best];
+      }
+      for (int k = 0; k < 3; ++k) { g.n[k] = 1 << bits[k]; g.inv[k] = (float)g.n[k] / ext[k]; }
+      g.pad = 0;
+    };
+    make_grid(s->sort_grid, 12);
   }
   *out = s;
   return RT_OK;

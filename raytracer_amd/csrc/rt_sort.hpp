@@ -26,13 +26,19 @@ struct SortGrid {                     // cell of p: clamp((p - lo) * inv, 0, n -
   int32_t pad;
 };
 
-__device__ __forceinline__ void sort_range(const Counters* C, const FrameParams& fp, int level, uint32_t* begin, uint32_t* end) {
-  uint32_t count = C->n_hits[level];
+__device__ __forceinline__ void sort_range(uint32_t count, const FrameParams& fp, uint32_t* begin, uint32_t* end) {
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t chunk = (count + SORT_BLOCKS - 1) / SORT_BLOCKS;
   const uint32_t b = blockIdx.x * chunk;
   *begin = b < count ? b : count;
   *end = b + chunk < count ? b + chunk : count;
+}
+
+__device__ __forceinline__ uint32_t sort_cell(const SortGrid& g, float px, float py, float pz) {
+  const int cx = (int)fminf(fmaxf((px - g.lo[0]) * g.inv[0], 0.0f), (float)(g.n[0] - 1));
+  const int cy = (int)fminf(fmaxf((py - g.lo[1]) * g.inv[1], 0.0f), (float)(g.n[1] - 1));
+  const int cz = (int)fminf(fmaxf((pz - g.lo[2]) * g.inv[2], 0.0f), (float)(g.n[2] - 1));
+  return (uint32_t)((cx * g.n[1] + cy) * g.n[2] + cz);
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, FrameParams fp, int level, RayQueue q,
@@ -42,16 +48,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, Fram
   for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) s_hist[b] = 0u;
   __syncthreads();
   uint32_t begin, end;
-  sort_range(C, fp, level, &begin, &end);
+  sort_range(C->n_hits[level], fp, &begin, &end);
   for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
     const HitRec hr = hits[i];
     const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
     const float px = (float)(r.o.x + hr.t * r.d.x), py = (float)(r.o.y + hr.t * r.d.y), pz = (float)(r.o.z + hr.t * r.d.z);
     // (NaN / inf -> cell 0 or the last one: fminf/fmaxf drop NaNs, the conversion saturates)
-    const int cx = (int)fminf(fmaxf((px - g.lo[0]) * g.inv[0], 0.0f), (float)(g.n[0] - 1));
-    const int cy = (int)fminf(fmaxf((py - g.lo[1]) * g.inv[1], 0.0f), (float)(g.n[1] - 1));
-    const int cz = (int)fminf(fmaxf((pz - g.lo[2]) * g.inv[2], 0.0f), (float)(g.n[2] - 1));
-    const uint32_t key = (uint32_t)((cx * g.n[1] + cy) * g.n[2] + cz);
+    const uint32_t key = sort_cell(g, px, py, pz);
     keys[i] = (uint16_t)key;
     atomicAdd(&s_hist[key], 1u);
   }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(FrameParams fp, i
   for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) s_cur[b] = table[(size_t)b * SORT_BLOCKS + blockIdx.x];
   __syncthreads();
   uint32_t begin, end;
-  sort_range(C, fp, level, &begin, &end);
+  sort_range(C->n_hits[level], fp, &begin, &end);
   for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
     const uint32_t pos = atomicAdd(&s_cur[keys[i]], 1u);
     out[pos] = hits[i];

@@ -102,3 +102,30 @@ def test_numpy_stream_and_sequential_on_large_scene(oracle):
     img = render_hip(cam, st, mats, surfs, lights, 48, 27, jitter=("pixel", 5), sequential=True, verbose=False)
     ref = oracle.render(cam, st, mats, surfs, lights, 48, 27, jitter=("pixel", 5), sequential=True)
     assert rel_err(img, ref).max() < 1e-9
+
+
+def test_regrouping_of_hits_changes_nothing():
+    """rt_sort.hpp: the hits of level >= 1 are regrouped by the grid cell of the hit point before the
+    shade kernel.  That is scheduling only: ray / hit / shadow-ray counts are identical and the images
+    agree to the rounding of the framebuffer's accumulation order with the step switched off
+    (RT_SORT_HITS=0)."""
+    from raytracer_amd.render import render_hip
+    cam, st, mats, surfs, lights = _scene(1500, 200, seed=4, n=2, depth=4)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["RT_SORT_HITS"] = mode
+        try:
+            s64, s32 = {}, {}
+            out[mode] = (render_hip(cam, st, mats, surfs, lights, 160, 90, jitter=("pixel", 9), stats=s64, verbose=False),
+                         render_hip(cam, st, mats, surfs, lights, 160, 90, jitter=("pixel", 9), precision="fp32", stats=s32, verbose=False),
+                         s64, s32)
+        finally:
+            os.environ.pop("RT_SORT_HITS", None)
+    base, o = out["0"], out["1"]
+    assert base[2]["rays"] > 160 * 90 * 1.5          # deeper levels exist
+    for k in ("rays", "hits", "shadow_rays", "segments"):
+        assert o[2][k] == base[2][k], k
+    for k in ("rays", "hits"):
+        assert o[3][k] == base[3][k], k
+    assert rel_err(o[0], base[0]).max() < 1e-14
+    assert np.abs(o[1] - base[1]).max() < 1e-5

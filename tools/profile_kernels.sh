@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 kernel-trace summaries of the frame kernels (run on the GPU box):
+#   tools/profile_kernels.sh [outdir]
+# writes <outdir>/<workload>_kernel_stats.csv for the four workloads of tools/quick_bench.py and
+# <outdir>/bench_pool4k_rocprof.json (bench.py's own line measured under the profiler).
+set -u
+OUT=${1:-/root/repo/gpurun_out/kstats}
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for w in pool4k original1080 pool8k synth4k; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -- \
+    python3 /root/repo/tools/quick_bench.py "$w" --frames 3 > "$OUT/$w.log" 2>&1 || { echo "$w failed"; tail -5 "$OUT/$w.log"; exit 1; }
+  cp "$(ls "$OUT/$w"/*/*kernel_stats.csv | head -1)" "$OUT/${w}_kernel_stats.csv" && echo "$w ok"
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- \
+  python3 /root/repo/bench.py --no-cpu-baseline > "$OUT/bench_pool4k_rocprof.json" 2> "$OUT/bench.log" || { echo "bench failed"; tail -5 "$OUT/bench.log"; exit 1; }
+cp "$(ls "$OUT/bench"/*/*kernel_stats.csv | head -1)" "$OUT/bench_pool4k_kernel_stats.csv" && echo "bench ok"
