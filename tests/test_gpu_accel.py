@@ -129,3 +129,41 @@ def test_regrouping_of_hits_changes_nothing():
         assert o[3][k] == base[3][k], k
     assert rel_err(o[0], base[0]).max() < 1e-14
     assert np.abs(o[1] - base[1]).max() < 1e-5
+
+
+def test_far_hits_keep_the_culling_conservative():
+    """A camera just above the floor whose pixel row above the centre looks 1e-6 rad below the horizon:
+    primary (and reflected) rays hit the infinite floor ~1e6 units away.  The fan culling of
+    k_shade_fast is parametrised from the light end so that such hits neither lose precision nor turn
+    every record into a candidate (rt_shade_fast.hpp).  Whatever it skips must not contribute: against
+    the exact fp64 image the culled fp32 image is nowhere worse than the brute-force mode's (RT_ACCEL=0).
+    (It is better on the far row: there the fp32 sphere roots of the brute-force loop cancel, |oc|^2 ~ 1e12,
+    and report spurious crossings of spheres that the light-end test has already excluded.)"""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.render import render_hip, camera_rays, nearest_hit
+    from raytracer_amd.synth import synthetic_scene_text
+    W, H = 192, 108
+    step = 1.6 / W                                        # pixel pitch on the screen (screen_width 1.6)
+    tan_pitch = (0.5 * step + 1.4e-6) / 1.4               # screen distance 1.4
+    lines = synthetic_scene_text(700, 100, shadow_rays=3, max_recursions=3, seed=12).splitlines()
+    ci = next(i for i, l in enumerate(lines) if l.startswith("cam "))
+    lines[ci] = f"cam 0.0 0.3 -75.0 0.0 {0.3 - 75.0 * tan_pitch!r} 0.0 0.0 1.0 0.0 1.4 1.6"
+    cam, st, objs = parse_scene_text("\n".join(lines) + "\n")
+    mats, surfs, lights = separate_objects(objs)
+    cam.setup(W / H)
+    o, d = camera_rays(cam, W, H, H // 2 - 1, H // 2)
+    t, idx, _ = nearest_hit(surfs, o, d)
+    assert (idx >= 0).any() and t[idx >= 0].max() > 1e5   # the frame holds far floor hits
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["RT_ACCEL"] = mode
+        try:
+            out[mode] = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 3), precision="fp32", verbose=False)
+        finally:
+            os.environ.pop("RT_ACCEL", None)
+    ref = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 3), verbose=False)
+    err_accel, err_brute = np.abs(out["1"] - ref), np.abs(out["0"] - ref)
+    assert (err_accel <= err_brute + 2e-6).all()
+    assert (np.abs(_q(out["1"]) - _q(ref)) <= 1).mean() >= 0.995
+    far_row = H // 2 - 1
+    print(f"far row: max |fp32 - fp64| culled {err_accel[far_row].max():.2e}, brute force {err_brute[far_row].max():.2e}")
