@@ -167,3 +167,23 @@ def test_far_hits_keep_the_culling_conservative():
     assert (np.abs(_q(out["1"]) - _q(ref)) <= 1).mean() >= 0.995
     far_row = H // 2 - 1
     print(f"far row: max |fp32 - fp64| culled {err_accel[far_row].max():.2e}, brute force {err_brute[far_row].max():.2e}")
+
+
+def test_hierarchy_larger_than_the_lds_staging(oracle):
+    """More than 1024 nodes: the hierarchy is not staged in LDS, the walks read it from global memory
+    (load_node's second branch).  RT_BVH_LEAF=1 gives every record its own leaf, so 1400 records make
+    ~1600 nodes."""
+    from raytracer_amd.render import render_hip
+    cam, st, mats, surfs, lights = _scene(1200, 200, seed=6, n=2, depth=3)
+    os.environ["RT_BVH_LEAF"] = "1"
+    try:
+        stats = {}
+        img = render_hip(cam, st, mats, surfs, lights, 80, 45, jitter=("pixel", 4), stats=stats, verbose=False)
+        img32 = render_hip(cam, st, mats, surfs, lights, 80, 45, jitter=("pixel", 4), precision="fp32", verbose=False)
+    finally:
+        os.environ.pop("RT_BVH_LEAF", None)
+    ref, ost = oracle.render(cam, st, mats, surfs, lights, 80, 45, jitter=("pixel", 4), return_stats=True)
+    for k in ("rays", "hits", "shadow_rays", "segments"):
+        assert stats[k] == ost[k], k
+    assert rel_err(img, ref).max() < 1e-12
+    assert (np.abs(_q(img32) - _q(ref)) <= 1).mean() >= 0.995
