@@ -156,6 +156,39 @@ void morton_sort(std::vector<Prim>& prims, int first, int count) {
   for (int i = 0; i < count; ++i) tmp[i] = prims[first + key[i].second];
   std::copy(tmp.begin(), tmp.end(), prims.begin() + first);
 }
+
+// Order of the records [first, first+count) that makes every group the builder forms (leaf * fanout^k
+// consecutive records, BvhBuilder::build) spatially compact: the range is bisected at group
+// boundaries along the longest axis of its centres (nth_element), recursively down to the leaves.
+// Unlike a Morton order it has no curve jumps inside a group, so the node boxes are tighter.
+void median_order(std::vector<Prim>& prims, std::vector<BoundD>& ctr, int first, int count, int leaf, int fanout);
+static void median_split(std::vector<Prim>& prims, std::vector<BoundD>& ctr, int first, int count, int group) {
+  const int ngroups = (count + group - 1) / group;
+  if (ngroups <= 1) return;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = first; i < first + count; ++i)
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], ctr[i].c[k]); hi[k] = std::max(hi[k], ctr[i].c[k]); }
+  int axis = 0;
+  for (int k = 1; k < 3; ++k) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+  const int left = (ngroups / 2) * group;
+  std::vector<int> idx(count);
+  for (int i = 0; i < count; ++i) idx[i] = first + i;
+  std::nth_element(idx.begin(), idx.begin() + left, idx.end(), [&](int a, int b) {
+    return ctr[a].c[axis] < ctr[b].c[axis] || (ctr[a].c[axis] == ctr[b].c[axis] && a < b); });
+  std::vector<Prim> tp(count); std::vector<BoundD> tc(count);
+  for (int i = 0; i < count; ++i) { tp[i] = prims[idx[i]]; tc[i] = ctr[idx[i]]; }
+  std::copy(tp.begin(), tp.end(), prims.begin() + first);
+  std::copy(tc.begin(), tc.end(), ctr.begin() + first);
+  median_split(prims, ctr, first, left, group);
+  median_split(prims, ctr, first + left, count - left, group);
+}
+void median_order(std::vector<Prim>& prims, std::vector<BoundD>& ctr, int first, int count, int leaf, int fanout) {
+  if (count <= leaf) return;
+  long long child = leaf; while (child * fanout < count) child *= fanout;       // the builder's group size at this level
+  median_split(prims, ctr, first, count, (int)child);
+  for (long long off = 0; off < count; off += child)
+    median_order(prims, ctr, first + (int)off, (int)std::min<long long>(child, count - off), leaf, fanout);
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------- scene ---------
@@ -249,18 +282,31 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       ++cnt[type];
     }
   // large scenes: Morton order inside the sphere / box ranges + culling hierarchy (RT_ACCEL=0: brute force)
+  float accel_lo[3] = {0, 0, 0}, accel_hi[3] = {0, 0, 0}; int sphere_nodes = 0;   // union of the hierarchy's root boxes
   std::vector<BvhNode> nodes;
   std::vector<float4> pbound;
   {
     const char* e = getenv("RT_ACCEL");
     const bool want = !(e && e[0] == '0');
     if (want && (int)prims.size() > LDS_PRIMS && cnt[0] + cnt[2] > 0 && prims.size() < (1u << 27)) {
-      morton_sort(prims, 0, cnt[0]);
-      morton_sort(prims, cnt[0] + cnt[1], cnt[2]);
       BvhBuilder bb(prims);
+      const char* ord = getenv("RT_BVH_ORDER");
+      if (ord && ord[0] == 'm') {                       // A/B: Morton order of the centres
+        morton_sort(prims, 0, cnt[0]);
+        morton_sort(prims, cnt[0] + cnt[1], cnt[2]);
+      } else {
+        std::vector<BoundD> ctr(prims.size());
+        for (size_t i = 0; i < prims.size(); ++i) if (prims[i].type != RT_PLANE) ctr[i] = prim_bound(prims[i]);
+        median_order(prims, ctr, 0, cnt[0], bb.leaf, bb.fanout);
+        median_order(prims, ctr, cnt[0] + cnt[1], cnt[2], bb.leaf, bb.fanout);
+      }
       if (cnt[0] > 0) bb.build(0, cnt[0]);
+      sphere_nodes = (int)bb.nodes.size();
       if (cnt[2] > 0) bb.build(cnt[0] + cnt[1], cnt[2]);
       nodes.swap(bb.nodes);
+      for (int k = 0; k < 3; ++k) { accel_lo[k] = 3.0e38f; accel_hi[k] = -3.0e38f; }
+      for (int root : {0, cnt[0] > 0 && cnt[2] > 0 ? sphere_nodes : 0})          // roots of the sphere and the box tree
+        for (int k = 0; k < 3; ++k) { accel_lo[k] = std::min(accel_lo[k], nodes[root].lo[k]); accel_hi[k] = std::max(accel_hi[k], nodes[root].hi[k]); }
       pbound.resize(prims.size());
       for (size_t i = 0; i < prims.size(); ++i)
         pbound[i] = prims[i].type == RT_PLANE ? make_float4(0, 0, 0, 3.0e38f) : to_float_bound(prim_bound(prims[i]));
@@ -311,14 +357,16 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.bg[k] = desc->background[k];
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
-  s->ds.all_opaque = s->all_opaque ? 1 : 0; s->ds.pad = 0;
+  s->ds.all_opaque = s->all_opaque ? 1 : 0;
+  s->ds.scene_m = 0.0f;       // L1 size of the hierarchy's bounds: scales the fp32 slack of k_shade_fast's node tests
+  for (int k = 0; k < 3; ++k) s->ds.scene_m += std::max(std::fabs(accel_lo[k]), std::fabs(accel_hi[k]));
   if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
   if (!nodes.empty() && !(getenv("RT_SORT_HITS") && atoi(getenv("RT_SORT_HITS")) == 0)) {
     // grid over the hierarchy's root box: 12 bits, each given to the axis whose cells are largest
     s->sort_hits = true;
     auto make_grid = [&](SortGrid& g, int total_bits) {
       float ext[3]; int bits[3] = {0, 0, 0};
-      for (int k = 0; k < 3; ++k) { g.lo[k] = nodes[0].lo[k]; ext[k] = std::max(nodes[0].hi[k] - nodes[0].lo[k], 1e-20f); }
+      for (int k = 0; k < 3; ++k) { g.lo[k] = accel_lo[k]; ext[k] = std::max(accel_hi[k] - accel_lo[k], 1e-20f); }
       for (int b = 0; b < total_bits; ++b) {
         int best = 0;
         for (int k = 1; k < 3; ++k) if (std::ldexp(ext[k], -bits[k]) > std::ldexp(ext[best], -bits[best])) best = k;

@@ -79,7 +79,8 @@ struct DevScene {
   int32_t nM, nL;
   double bg[3];
   Accel ac;
-  int32_t all_opaque, pad;   // every surface material has transparency == 0
+  int32_t all_opaque;        // every surface material has transparency == 0
+  float scene_m;             // sum over the axes of the largest |coordinate| of the culling hierarchy's bounds
 };
 constexpr int MAT_STRIDE = 12;
 constexpr int LIGHT_STRIDE = 12;

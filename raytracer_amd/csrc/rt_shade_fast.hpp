@@ -58,12 +58,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
   int* const wl = s_wleaves + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_LEAF_CAP);
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
-  float scene_m = 0.0f;            // L1 size of the hierarchy's root box: scales the fp32 slack of the node tests
-  if (!LDS_SCENE && ac.n_nodes > 0) {
-    const BvhNode root = load_node(ac, 0);
-    scene_m = fmaxf(fabsf(root.lo[0]), fabsf(root.hi[0])) + fmaxf(fabsf(root.lo[1]), fabsf(root.hi[1])) +
-              fmaxf(fabsf(root.lo[2]), fabsf(root.hi[2]));
-  }
+  const float scene_m = sc.scene_m;   // scales the fp32 slack of the node tests
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t lane = __lane_id();
