@@ -35,7 +35,7 @@ static_assert(sizeof(Prim) == 64, "Prim must be 64 bytes");
 // surviving primitive goes through the same exact test as in the brute-force loop; ties are still
 // broken by (t, orig).  Nodes are stored in depth-first order with skip links, so a lane walks the
 // tree without a stack: hit -> next node, miss -> node.skip.  Leaves own <= 8 consecutive records
-// of ONE type (spheres and boxes are Morton-sorted inside their type range); planes are unbounded
+// of ONE type (spheres and boxes are median-split ordered inside their type range); planes are unbounded
 // and stay outside the tree (always tested).
 struct __attribute__((aligned(16))) BvhNode {
   float lo[3], hi[3];      // axis-aligned bounds (rounded outward on the host)
