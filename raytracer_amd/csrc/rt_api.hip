@@ -514,7 +514,8 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     if (s->sort_hits) {
       HIPCHK(hipMalloc(&s->d_hits_sorted, q * sizeof(HitRec)));
       HIPCHK(hipMalloc(&s->d_sort_keys, q * sizeof(uint16_t)));
-      HIPCHK(hipMalloc(&s->d_sort_table, (size_t)SORT_BINS * SORT_BLOCKS * sizeof(uint32_t)));
+      // table[bin][block] followed by the per-bin totals
+      HIPCHK(hipMalloc(&s->d_sort_table, ((size_t)SORT_BINS * SORT_BLOCKS + SORT_BINS) * sizeof(uint32_t)));
     }
     for (int i = 0; i < 2; ++i) {
       HIPCHK(hipMalloc(&s->d_qbuf[i], q * 9 * sizeof(double)));
@@ -585,9 +586,11 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
     const HitRec* level_hits = s->d_hits;
     if (s->sort_hits && level >= 1) {
       Timed t(s, pf, 2);
+      uint32_t* bin_total = s->d_sort_table + (size_t)SORT_BINS * SORT_BLOCKS;
+      hipMemsetAsync(bin_total, 0, SORT_BINS * sizeof(uint32_t), s->stream);
       hipLaunchKernelGGL(k_sort_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, cam, fp, level, cur, s->d_hits,
-                         s->d_counters, s->sort_grid, s->d_sort_keys, s->d_sort_table);
-      hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_THREADS), 0, s->stream, s->d_sort_table);
+                         s->d_counters, s->sort_grid, s->d_sort_keys, s->d_sort_table, bin_total);
+      hipLaunchKernelGGL(k_sort_scan, dim3(SORT_BINS / SCAN_BINS), dim3(SCAN_THREADS), 0, s->stream, s->d_sort_table, bin_total);
       hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, fp, level, s->d_hits, s->d_counters,
                          s->d_sort_keys, s->d_sort_table, s->d_hits_sorted);
       level_hits = s->d_hits_sorted;

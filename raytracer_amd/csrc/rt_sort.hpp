@@ -9,8 +9,9 @@
 // updates are atomic adds), so this is a pure scheduling step — it has no counterpart in the
 // reference, whose batches are NumPy arrays in parent order (ray_tracer.py:491-515).
 //
-// Three launches, no global atomics: per-block histograms in LDS -> table[bin][block], one-block
-// exclusive scan of the table (bin-major = final order), scatter with LDS cursors.
+// Three launches: per-block histograms in LDS -> table[bin][block] (+ per-bin totals, one global atomic
+// per non-empty (block, bin)), exclusive scan of the table in bin-major order = final order (one block
+// per 32 bins; its base is the sum of the totals of the bins before), scatter with LDS cursors.
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -43,7 +44,8 @@ __device__ __forceinline__ uint32_t sort_cell(const SortGrid& g, float px, float
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                              const HitRec* __restrict__ hits, const Counters* C, SortGrid g,
-                                                             uint16_t* __restrict__ keys, uint32_t* __restrict__ table) {
+                                                             uint16_t* __restrict__ keys, uint32_t* __restrict__ table,
+                                                             uint32_t* __restrict__ bin_total) {
   __shared__ uint32_t s_hist[SORT_BINS];
   for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) s_hist[b] = 0u;
   __syncthreads();
@@ -59,32 +61,52 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, Fram
     atomicAdd(&s_hist[key], 1u);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) table[(size_t)b * SORT_BLOCKS + blockIdx.x] = s_hist[b];
+  for (int b = threadIdx.x; b < SORT_BINS; b += SORT_THREADS) {
+    const uint32_t c = s_hist[b];
+    table[(size_t)b * SORT_BLOCKS + blockIdx.x] = c;
+    if (c) atomicAdd(&bin_total[b], c);            // bin_total is zeroed by the host before this launch
+  }
 }
 
-// Exclusive scan of table[SORT_BINS * SORT_BLOCKS] in place (one block; 2 MiB, L2-resident).
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(uint32_t* __restrict__ table) {
-  constexpr int PER = SORT_BINS * SORT_BLOCKS / SORT_THREADS;      // consecutive entries per thread
-  static_assert(PER % 4 == 0, "scan reads uint4");
-  __shared__ uint32_t s_sum[SORT_THREADS];
-  uint4* mine = reinterpret_cast<uint4*>(table + (size_t)threadIdx.x * PER);
-  uint32_t sum = 0;
-  for (int i = 0; i < PER / 4; ++i) { const uint4 v = mine[i]; sum += (v.x + v.y) + (v.z + v.w); }
+// Exclusive scan of table[SORT_BINS * SORT_BLOCKS] in place, bin-major.  Block g owns SCAN_BINS bins
+// (SCAN_BINS * SORT_BLOCKS consecutive entries, one per thread-quad); its base is the sum of bin_total over
+// the bins before its first one.
+constexpr int SCAN_BINS = 32;
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void k_sort_scan(uint32_t* __restrict__ table, const uint32_t* __restrict__ bin_total) {
+  constexpr int PER = SCAN_BINS * SORT_BLOCKS / SCAN_THREADS;        // consecutive entries per thread
+  static_assert(PER == 4, "one uint4 per thread");
+  __shared__ uint32_t s_sum[SCAN_THREADS];
+  __shared__ uint32_t s_base;
+  const int first_bin = blockIdx.x * SCAN_BINS;
+  // base: totals of the bins before this block's (<= 4096 values, summed by the whole block)
+  uint32_t part = 0;
+  for (int b = threadIdx.x; b < first_bin; b += SCAN_THREADS) part += bin_total[b];
+  s_sum[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = SCAN_THREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < (unsigned)o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_base = s_sum[0];
+  __syncthreads();
+  const uint32_t base = s_base;
+  __syncthreads();
+  uint4* mine = reinterpret_cast<uint4*>(table + (size_t)first_bin * SORT_BLOCKS) + threadIdx.x;
+  const uint4 v = *mine;
+  const uint32_t sum = (v.x + v.y) + (v.z + v.w);
   s_sum[threadIdx.x] = sum;
   __syncthreads();
-  for (int o = 1; o < SORT_THREADS; o <<= 1) {                      // Hillis-Steele inclusive scan of the sums
+  for (int o = 1; o < SCAN_THREADS; o <<= 1) {                       // Hillis-Steele inclusive scan of the sums
     const uint32_t add = threadIdx.x >= (unsigned)o ? s_sum[threadIdx.x - o] : 0u;
     __syncthreads();
     s_sum[threadIdx.x] += add;
     __syncthreads();
   }
-  uint32_t run = s_sum[threadIdx.x] - sum;
-  for (int i = 0; i < PER / 4; ++i) {
-    const uint4 v = mine[i];
-    uint4 o;
-    o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
-    mine[i] = o;
-  }
+  uint32_t run = base + s_sum[threadIdx.x] - sum;
+  uint4 o;
+  o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run;
+  *mine = o;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(FrameParams fp, int level, const HitRec* __restrict__ hits,
