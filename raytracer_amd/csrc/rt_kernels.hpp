@@ -80,7 +80,7 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
 
 // Small hierarchies (<= LDS_NODES nodes, 32 KiB) are staged in LDS too: the walk is a chain of
 // dependent loads, LDS latency is several times shorter than L2's.
-constexpr int LDS_NODES = 1024;
+constexpr int LDS_NODES = 1016;     // (just under 32 KiB: k_trace's nodes + hit staging then fit four workgroups per CU)
 template <bool LDS_SCENE>
 __device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   Accel a = sc.ac;
@@ -178,19 +178,21 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
                                                  HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
   __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
-  __shared__ HitRec s_hits[TRACE_CHUNK];
+  // large scenes: half-size chunks, so that nodes + staging leave room for 4 workgroups per CU
+  constexpr int CHUNK = LDS_SCENE ? TRACE_CHUNK : TRACE_CHUNK / 2;
+  __shared__ HitRec s_hits[CHUNK];
   __shared__ uint32_t s_count, s_base;
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   uint32_t count = C->n_rays[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
-  const uint32_t n_chunks = (count + TRACE_CHUNK - 1) / TRACE_CHUNK;
+  const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
 #pragma unroll 1
-    for (int it = 0; it < TRACE_CHUNK / BLOCK; ++it) {
-      const uint32_t slot = chunk * TRACE_CHUNK + it * BLOCK + threadIdx.x;
+    for (int it = 0; it < CHUNK / BLOCK; ++it) {
+      const uint32_t slot = chunk * CHUNK + it * BLOCK + threadIdx.x;
       const bool active = slot < count;
       bool hit = false;
       int k = -1; double t = RT_INF;
