@@ -456,8 +456,8 @@ static int drain(rt_scene* s) {
         fprintf(stderr, "[rt debug] k_shade_fast large-scene walks (wave, light): %llu; wave-level steps per walk: %.1f node tests, %.1f leaves, %.2f sample blocks\n",
                 (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
       else if (bits & 128)
-        fprintf(stderr, "[rt debug] k_shade_fast wave leaf lists (wave, light): %llu, %.3f too long, %.1f leaves on average\n",
-                (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0);
+        fprintf(stderr, "[rt debug] k_shade_fast wave leaf lists (wave, light): %llu, %.3f too long, %.1f leaves and %.1f records on average\n",
+                (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
       else
         fprintf(stderr, "[rt debug] k_shade_fast hierarchy walks (hit, light): %llu; per walk: %.1f nodes tested (holding %.1f record bounds), %.2f records processed\n",
                 (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);

@@ -45,7 +45,8 @@ __device__ __forceinline__ f3 normalize_clamped(f3 a) {   // v / max(|v|, 1e-6)
 constexpr float T_LO = 2e-6f;   // see header: 1e-6 origin shift + 1e-6 hit threshold
 
 constexpr int LEAF_LIST = 20, CAND_LIST = 16;   // per-lane lists of the large-scene walk (entries, in LDS)
-constexpr int WAVE_LEAF_CAP = 64;     // leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves
+constexpr int WAVE_LEAF_CAP = 64;
+constexpr int WAVE_REC_CAP = 128;     // records a (wave, light) list holds; more: the lanes test their leaves' bounds themselves     // leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves
 
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCENE && CH <= 9) ? 2 : 1))) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
   __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];
   __shared__ uint32_t s_leaf[LDS_SCENE ? 1 : LEAF_LIST * BLOCK], s_cand[LDS_SCENE ? 1 : CAND_LIST * BLOCK];
   int* const wl = s_wleaves + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_LEAF_CAP);
+  __shared__ int s_wrecs[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_REC_CAP];
+  int* const wr = s_wrecs + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_REC_CAP);
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   const float scene_m = sc.scene_m;   // scales the fp32 slack of the node tests
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           skip_samples = !(RT_DBG(fp) & 2u) && !__any(fc.lane_can & !fc.lane_full);
         }
         if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
-        int n_wl = -1;
+        int n_wl = -1, n_wr = -1;
         if (coop) {
           // segment cw -> Lp against the node box grown by max(rho, RL) (+ fp32 slack), 0 <= tau <= 1
           const f3 tw = mkf((float)lg[0] - cw.x, (float)lg[1] - cw.y, (float)lg[2] - cw.z);
@@ -161,8 +164,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float tf2 = fminf(fminf(fmaxf(ax2, bx2), fmaxf(ay2, by2)), fminf(fmaxf(az2, bz2), 1.0f));
             return tn2 <= tf2 + 1e-5f;
           }, wl, WAVE_LEAF_CAP);
+          // Second wave-level step: the records of those leaves, 64 bounds per round (lane = leaf slot * 8 +
+          // record), against the hull of the wave's fans: the cone from the ball (cw, rho) to the ball
+          // (Lp, RLw).  The lanes then test the surviving records' bounds with their own fan and skip the
+          // per-lane node and leaf steps altogether.
+          if (n_wl >= 0 && !(RT_DBG(fp) & 512u)) {
+            const float T0w = dotf(tw, tw), dlw = RLw - rho;
+            const float qaw = T0w - dlw * dlw, rqaw = raw_rcp(qaw);
+            n_wr = 0;
+            for (int l0 = 0; l0 < n_wl && n_wr >= 0; l0 += 8) {
+              const int slot = l0 + (int)(lane >> 3), j = (int)(lane & 7u);
+              bool may = false; int rec = 0;
+              if (slot < n_wl) {
+                const BvhNode nd = load_node(ac, wl[slot]);
+                if (j < nd.count()) {
+                  rec = nd.first + j;
+                  const float4 b = ac.pbound[rec];
+                  const f3 ow = mkf(cw.x - b.x, cw.y - b.y, cw.z - b.z);
+                  const float w0 = b.w + rho + gs;
+                  const float o2 = dotf(ow, ow), qb = dotf(ow, tw) - w0 * dlw;
+                  const float tau = fminf(fmaxf(-qb * rqaw, 0.0f), 1.0f);
+                  const float g = fmaf(tau, fmaf(tau, qaw, 2.0f * qb), o2 - w0 * w0);      // min of |ow + tau tw|^2 - (w0 + tau dlw)^2
+                  may = (qaw <= 0.0f) | (g <= 1e-4f * (T0w + o2 + w0 * w0 + 1.0f));
+                }
+              }
+              const unsigned long long m = __ballot(may);
+              const int cnt = __popcll(m);
+              if (n_wr + cnt > WAVE_REC_CAP) { n_wr = -1; break; }
+              if (may) wr[n_wr + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
+              n_wr += cnt;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
           if ((RT_DBG(fp) & 128u) && lane == 0) {
             atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], n_wl < 0 ? 1ull : 0ull); atomicAdd(&C->dbg[2], (unsigned long long)(n_wl < 0 ? 0 : n_wl));
+            atomicAdd(&C->dbg[3], (unsigned long long)(n_wr < 0 ? 0 : n_wr));
           }
         }
         for (int c = 0; c < (skip_samples ? 0 : n_chunks); ++c) {
@@ -300,6 +338,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             //      records that pass go to the lane's candidate list;
             //   3. every lane takes one candidate per step: the exact sample block.
             // Lists are bounded: a full leaf list pauses phase 1, a nearly full candidate list pauses phase 2.
+            // When the wave has a record list (compact wave: the usual case after the regrouping of
+            // rt_sort.hpp), phases 1 and 2 shrink to one bound test per listed record.
             uint32_t* const my_leaf = s_leaf + threadIdx.x;       // entry e at [e * BLOCK]
             uint32_t* const my_cand = s_cand + threadIdx.x;
             const int n_nodes = ac.n_nodes;
@@ -308,9 +348,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             int n_leaf = 0, le = 0, n_cand = 0;
             unsigned it1 = 0, it2 = 0, it3 = 0;
             long long ck1 = 0, ck2 = 0, ck3 = 0, ck0 = (RT_DBG(fp) & 2048u) ? clock64() : 0;
-            for (;;) {
-              if (!__any(le < n_leaf)) {
-                if (!__any(wi < w_end)) break;
+            int we = 0;                     // position in the wave's record list
+            bool finished = false;
+            while (!finished) {
+              if (n_wr >= 0) {
+                // the wave's record list: each lane keeps the records its own fan may touch
+                for (; we < n_wr && !__any(n_cand >= CAND_LIST); ++we) {
+                  const int k = wr[we];
+                  const float4 b = ac.pbound[k];
+                  if (RT_DBG(fp)) ++it2;
+                  if (fan_may_touch(b.x, b.y, b.z, b.w)) { my_cand[n_cand * BLOCK] = (uint32_t)k; ++n_cand; }
+                }
+                finished = we >= n_wr;
+              } else if (!__any(le < n_leaf)) {
+                if (!__any(wi < w_end)) finished = true;       // (the candidate lists are empty here)
+                else {
                 n_leaf = 0; le = 0;
                 if (n_wl >= 0) {
                   for (; wi < n_wl && !__any(n_leaf >= LEAF_LIST); ++wi) {
@@ -333,10 +385,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
                     }
                   }
                 }
+                }
               }
               if (RT_DBG(fp) & 2048u) { const long long t = clock64(); ck1 += t - ck0; ck0 = t; }
               if (RT_DBG(fp) & 16u) n_leaf = 0;
-              while (__any(le < n_leaf) && !__any(n_cand > CAND_LIST - 8)) {
+              while (n_wr < 0 && __any(le < n_leaf) && !__any(n_cand > CAND_LIST - 8)) {
                 if (le < n_leaf) {
                   const uint32_t packed = my_leaf[le * BLOCK];
                   const int first = (int)(packed & 0x0FFFFFFFu), nj = (int)(packed >> 28);
