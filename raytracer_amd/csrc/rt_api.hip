@@ -213,6 +213,7 @@ struct rt_scene {
   int num_cu = 256;
   DevScene ds{};
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
+  int32_t* d_cut = nullptr;
   BvhNode* d_nodes = nullptr; float4* d_pbound = nullptr;   // culling hierarchy (large scenes only)
   bool all_opaque = true;
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
@@ -284,6 +285,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     }
   // large scenes: median-split order inside the sphere / box ranges + culling hierarchy (RT_ACCEL=0: brute force)
   float accel_lo[3] = {0, 0, 0}, accel_hi[3] = {0, 0, 0}; int sphere_nodes = 0;   // union of the hierarchy's root boxes
+  std::vector<int32_t> cut;        // <= 64 nodes covering both trees: entry points of the wave-level scan
   std::vector<BvhNode> nodes;
   std::vector<float4> pbound;
   {
@@ -308,6 +310,20 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       for (int k = 0; k < 3; ++k) { accel_lo[k] = 3.0e38f; accel_hi[k] = -3.0e38f; }
       for (int root : {0, cnt[0] > 0 && cnt[2] > 0 ? sphere_nodes : 0})          // roots of the sphere and the box tree
         for (int k = 0; k < 3; ++k) { accel_lo[k] = std::min(accel_lo[k], nodes[root].lo[k]); accel_hi[k] = std::max(accel_hi[k], nodes[root].hi[k]); }
+      // cut: start from the roots, replace inner nodes by their children level by level while <= 64 nodes
+      cut.push_back(0);
+      if (cnt[0] > 0 && cnt[2] > 0) cut.push_back(sphere_nodes);
+      for (;;) {
+        std::vector<int32_t> next;
+        bool expanded = false;
+        for (int32_t i : cut) {
+          if (nodes[i].count() > 0) { next.push_back(i); continue; }
+          for (int c = i + 1; c < nodes[i].skip(); c = nodes[c].skip()) next.push_back(c);
+          expanded = true;
+        }
+        if (!expanded || next.size() > 64) break;
+        cut.swap(next);
+      }
       pbound.resize(prims.size());
       for (size_t i = 0; i < prims.size(); ++i)
         pbound[i] = prims[i].type == RT_PLANE ? make_float4(0, 0, 0, 3.0e38f) : to_float_bound(prim_bound(prims[i]));
@@ -349,9 +365,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     HIPCHK_S(hipMalloc(&s->d_pbound, pbound.size() * sizeof(float4)));
     HIPCHK_S(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIPCHK_S(hipMemcpy(s->d_pbound, pbound.data(), pbound.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMalloc(&s->d_cut, 64 * sizeof(int32_t)));
+    HIPCHK_S(hipMemcpy(s->d_cut, cut.data(), cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
 #undef HIPCHK_S
   s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.lds_nodes = -1;
+  s->ds.ac.cut = s->d_cut; s->ds.ac.n_cut = (int)cut.size(); s->ds.ac.pad = 0;
   s->ds.prims = s->d_prims; s->ds.mats = s->d_mats; s->ds.lights = s->d_lights;
   s->ds.nS = cnt[0]; s->ds.nP = cnt[1]; s->ds.nB = cnt[2]; s->ds.n = (int)prims.size();
   s->ds.nM = desc->n_materials; s->ds.nL = desc->n_lights;
@@ -392,6 +411,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_lights) hipFree(s->d_lights);
   if (s->d_nodes) hipFree(s->d_nodes);
   if (s->d_pbound) hipFree(s->d_pbound);
+  if (s->d_cut) hipFree(s->d_cut);
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
   for (hipEvent_t e : s->event_pool) hipEventDestroy(e);

@@ -50,6 +50,8 @@ struct Accel {
   const float4* pbound;    // [n] bounding sphere of each record (planes: unused)
   int32_t n_nodes;
   int32_t lds_nodes;       // device side: LDS byte address of a staged copy of `nodes`, -1: none (host: -1)
+  const int32_t* cut;      // <= 64 nodes that cover the tree (every leaf is one of them or below one): entry
+  int32_t n_cut, pad;      // points of the wave-level scan (bvh_wave_leaves)
 };
 
 #ifdef __HIPCC__
@@ -302,34 +304,54 @@ __device__ __forceinline__ void bvh_walk(const Accel& ac, NodeHit node_hit, Prim
   }
 }
 
-// Wave-cooperative scan of the hierarchy: the 64 lanes test 64 consecutive nodes (depth-first order)
-// per round against ONE wave-uniform query (wave_node_hit), the leaves that pass are appended to a
-// per-wave list in LDS.  A missed inner node lets the scan jump to its skip link once the round is
-// over (descendants inside the same round are tested needlessly, which is harmless).  Returns the
-// number of leaves, or -1 when more than `cap` passed (the caller then walks per lane).  All 64
-// lanes must call this together.
+// Wave-cooperative scan of the hierarchy against ONE wave-uniform query (wave_node_hit): the leaves that
+// pass are appended to a per-wave list in LDS.  First the <= 64 nodes of the host-made cut are tested, one
+// per lane; then, for every inner cut node that passed, the 64 lanes test 64 consecutive nodes of its
+// subtree (depth-first order) per round; a missed inner node lets the scan jump to its skip link once the
+// round is over (descendants inside the same round are tested needlessly, which is harmless).  Returns the
+// number of leaves, or -1 when more than `cap` passed (the caller then walks per lane).  All 64 lanes must
+// call this together.
 template <class WaveNodeHit>
 __device__ __forceinline__ int bvh_wave_leaves(const Accel& ac, WaveNodeHit wave_node_hit, int* __restrict__ list, int cap) {
-  const int n = ac.n_nodes;
   const int lane = (int)__lane_id();
   int n_list = 0;
-  for (int r0 = 0; r0 < n;) {
-    const int i = r0 + lane;
-    bool leaf_hit = false; int jump = 0;
-    if (i < n) {
-      const BvhNode nd = load_node(ac, i);
-      const bool hit = wave_node_hit(nd);
-      leaf_hit = hit & (nd.count() > 0);
-      jump = hit ? 0 : nd.skip();
-    }
+  auto append = [&](bool leaf_hit, int i) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(leaf_hit);
     const int cnt = __popcll(m);
-    if (n_list + cnt > cap) return -1;
+    if (n_list + cnt > cap) return false;
     if (leaf_hit) list[n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
     n_list += cnt;
-#pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) jump = max(jump, __shfl_xor(jump, o_));
-    r0 = max(r0 + 64, jump);
+    return true;
+  };
+  int ci = -1, cskip = 0; bool chit = false, cleaf = false;
+  if (lane < ac.n_cut) {
+    ci = ac.cut[lane];
+    const BvhNode nd = load_node(ac, ci);
+    chit = wave_node_hit(nd);
+    cleaf = nd.count() > 0;
+    cskip = nd.skip();
+  }
+  if (!append(chit & cleaf, ci)) return -1;
+  unsigned long long inner = __ballot(chit & !cleaf);
+  while (inner) {
+    const int b = __ffsll((long long)inner) - 1;
+    inner &= inner - 1;
+    const int end = __builtin_amdgcn_readlane(cskip, b);
+    for (int r0 = __builtin_amdgcn_readlane(ci, b) + 1; r0 < end;) {
+      const int i = r0 + lane;
+      bool leaf_hit = false, far = false; int skip = 0;
+      if (i < end) {
+        const BvhNode nd = load_node(ac, i);
+        const bool hit = wave_node_hit(nd);
+        leaf_hit = hit & (nd.count() > 0);
+        skip = nd.skip();
+        far = !hit & (skip > r0 + 64);           // a missed subtree that reaches beyond this round
+      }
+      if (!append(leaf_hit, i)) return -1;
+      // nested missed subtrees: the outermost one belongs to the lowest lane
+      const unsigned long long fm = __ballot(far);
+      r0 = fm ? __builtin_amdgcn_readlane(skip, __ffsll((long long)fm) - 1) : r0 + 64;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
