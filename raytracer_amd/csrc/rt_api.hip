@@ -371,6 +371,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
 #undef HIPCHK_S
   s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.lds_nodes = -1;
   s->ds.ac.cut = s->d_cut; s->ds.ac.n_cut = (int)cut.size(); s->ds.ac.pad = 0;
+  for (int k = 0; k < 3; ++k) { s->ds.ac.lo[k] = accel_lo[k]; s->ds.ac.hi[k] = accel_hi[k]; }
   s->ds.prims = s->d_prims; s->ds.mats = s->d_mats; s->ds.lights = s->d_lights;
   s->ds.nS = cnt[0]; s->ds.nP = cnt[1]; s->ds.nB = cnt[2]; s->ds.n = (int)prims.size();
   s->ds.nM = desc->n_materials; s->ds.nL = desc->n_lights;

@@ -52,6 +52,7 @@ struct Accel {
   int32_t lds_nodes;       // device side: LDS byte address of a staged copy of `nodes`, -1: none (host: -1)
   const int32_t* cut;      // <= 64 nodes that cover the tree (every leaf is one of them or below one): entry
   int32_t n_cut, pad;      // points of the wave-level scan (bvh_wave_leaves)
+  float lo[3], hi[3];      // union of the root boxes
 };
 
 #ifdef __HIPCC__
@@ -224,8 +225,9 @@ struct PrimMask {
   __device__ __forceinline__ static PrimMask all() { PrimMask m; m.lo = m.hi = ~0ull; return m; }
 };
 
+template <bool WAVE = false>
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
-                                                int* k_out, double plane_thr);
+                                                int* k_out, double plane_thr, int* wave_list = nullptr, bool try_wave = true);
 __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out,
                                           double plane_thr = HIT_EPS, const Accel* ac = nullptr,
                                           PrimMask mask = PrimMask::all()) {
@@ -376,8 +378,17 @@ __device__ __forceinline__ bool ray_may_touch(float cx, float cy, float cz, floa
 
 // nearest() through the hierarchy: identical result (same exact tests, same (t, orig) rule), the
 // spheres/boxes that cannot be hit or cannot beat the current best are skipped.
+//
+// WAVE = true (k_trace; all 64 lanes must call together, wave_list = WAVE_LEAF_CAP ints of LDS per wave):
+// when the wave's rays are coherent — origins in a ball (cw, rho), unit directions within a cone around
+// their mean a, |u_i - a| <= kk — every point o_i + t u_i lies within rho + kk t of the axis point
+// cw + t a.  The hierarchy is then scanned ONCE per wave against that hull (bvh_wave_leaves) and each lane
+// tests only the listed leaves with its own ray: no dependent chain of node loads, and the leaf code runs
+// for all lanes together.  Scattered waves (cos < 0.9, or more than WAVE_LEAF_CAP leaves) walk per lane.
+constexpr int WAVE_LEAF_CAP = 64;     // leaves a per-wave list holds
+template <bool WAVE>
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
-                                                int* k_out, double plane_thr) {
+                                                int* k_out, double plane_thr, int* wave_list, bool try_wave) {
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   for (int k = nS, e = nS + nP; k < e; ++k) {
     double t = plane_t(P[k], o, d, plane_thr);
@@ -394,24 +405,83 @@ __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int 
   const float ix = fabsf(ux) > 1e-20f ? 1.0f / ux : 1e30f, iy = fabsf(uy) > 1e-20f ? 1.0f / uy : 1e30f,
               iz = fabsf(uz) > 1e-20f ? 1.0f / uz : 1e30f;
   const float dl = 4e-5f * (1.0f + fabsf(ofx) + fabsf(ofy) + fabsf(ofz));
-  bvh_walk(ac,
-    [&](const BvhNode& nd) __attribute__((always_inline)) {
-      const float ax = (nd.lo[0] - dl - ofx) * ix, bx = (nd.hi[0] + dl - ofx) * ix;
-      const float ay = (nd.lo[1] - dl - ofy) * iy, by = (nd.hi[1] + dl - ofy) * iy;
-      const float az = (nd.lo[2] - dl - ofz) * iz, bz = (nd.hi[2] + dl - ofz) * iz;
+  auto node_hit = [&](const BvhNode& nd) __attribute__((always_inline)) {
+    const float ax = (nd.lo[0] - dl - ofx) * ix, bx = (nd.hi[0] + dl - ofx) * ix;
+    const float ay = (nd.lo[1] - dl - ofy) * iy, by = (nd.hi[1] + dl - ofy) * iy;
+    const float az = (nd.lo[2] - dl - ofz) * iz, bz = (nd.hi[2] + dl - ofz) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_u));
+    return tn <= tf * 1.00001f + 1e-5f;
+  };
+  auto prim_may = [&](const float4& b) __attribute__((always_inline)) { return ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u); };
+  auto on_prim = [&](int k) __attribute__((always_inline)) {
+    const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
+    const int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) {
+      best = t; bk = k; borig = og;
+      tmax_u = (float)best * len * 1.00001f + 1e-5f;
+    }
+  };
+  int n_wl = -1;
+  if (WAVE && try_wave) {      // (try_wave is wave-uniform)
+    // parameter range of this ray inside the hierarchy's bounds (empty -> it can hit nothing in the tree)
+    float T_lane;
+    {
+      const float ax = (ac.lo[0] - dl - ofx) * ix, bx = (ac.hi[0] + dl - ofx) * ix;
+      const float ay = (ac.lo[1] - dl - ofy) * iy, by = (ac.hi[1] + dl - ofy) * iy;
+      const float az = (ac.lo[2] - dl - ofz) * iz, bz = (ac.hi[2] + dl - ofz) * iz;
       const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
       const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_u));
-      return tn <= tf * 1.00001f + 1e-5f;
-    },
-    [&](const float4& b) __attribute__((always_inline)) { return ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u); },
-    [&](int k) __attribute__((always_inline)) {
-      const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
-      const int og = P[k].orig;
-      if (t < best || (t == best && og < borig && bk >= 0)) {
-        best = t; bk = k; borig = og;
-        tmax_u = (float)best * len * 1.00001f + 1e-5f;
-      }
-    });
+      T_lane = (tn <= tf * 1.00001f + 1e-5f) ? tf * 1.00001f + 1e-5f : 0.0f;
+    }
+    float lox = ofx, loy = ofy, loz = ofz, hix = ofx, hiy = ofy, hiz = ofz, sx = ux, sy = uy, sz = uz, T = T_lane;
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+      lox = fminf(lox, __shfl_xor(lox, o_)); loy = fminf(loy, __shfl_xor(loy, o_)); loz = fminf(loz, __shfl_xor(loz, o_));
+      hix = fmaxf(hix, __shfl_xor(hix, o_)); hiy = fmaxf(hiy, __shfl_xor(hiy, o_)); hiz = fmaxf(hiz, __shfl_xor(hiz, o_));
+      sx += __shfl_xor(sx, o_); sy += __shfl_xor(sy, o_); sz += __shfl_xor(sz, o_);
+      T = fmaxf(T, __shfl_xor(T, o_));
+    }
+    const float cwx = 0.5f * (lox + hix), cwy = 0.5f * (loy + hiy), cwz = 0.5f * (loz + hiz);
+    const float s2 = fmaf(sz, sz, fmaf(sy, sy, sx * sx));
+    const float sinv = s2 > 1e-12f ? 1.0f / sqrtf(s2) : 0.0f;
+    const float axx = sx * sinv, axy = sy * sinv, axz = sz * sinv;                       // mean direction
+    float r2 = (ofx - cwx) * (ofx - cwx) + (ofy - cwy) * (ofy - cwy) + (ofz - cwz) * (ofz - cwz);
+    float cosm = fmaf(axz, uz, fmaf(axy, uy, axx * ux));
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { r2 = fmaxf(r2, __shfl_xor(r2, o_)); cosm = fminf(cosm, __shfl_xor(cosm, o_)); }
+    if (cosm > 0.9f && T < 1e30f) {
+      const float rho = sqrtf(r2) * 1.0001f + 4e-5f * (1.0f + fabsf(cwx) + fabsf(cwy) + fabsf(cwz));
+      const float kk = sqrtf(fmaxf(2.0f - 2.0f * cosm, 0.0f)) * 1.001f + 2e-5f;          // >= |u_i - a| for every lane
+      const float jx = fabsf(axx) > 1e-20f ? 1.0f / axx : 1e30f, jy = fabsf(axy) > 1e-20f ? 1.0f / axy : 1e30f,
+                  jz = fabsf(axz) > 1e-20f ? 1.0f / axz : 1e30f;
+      const float gT = fmaf(kk, T, rho);
+      n_wl = bvh_wave_leaves(ac, [&](const BvhNode& nd) __attribute__((always_inline)) {
+        const float ax = (nd.lo[0] - gT - cwx) * jx, bx = (nd.hi[0] + gT - cwx) * jx;
+        const float ay = (nd.lo[1] - gT - cwy) * jy, by = (nd.hi[1] + gT - cwy) * jy;
+        const float az = (nd.lo[2] - gT - cwz) * jz, bz = (nd.hi[2] + gT - cwz) * jz;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), T));
+        if (!(tn <= tf * 1.00001f + 1e-5f)) return false;
+        // the hull's radius grows with t and t <= tf inside this box: second test with the radius reached there
+        const float g2 = fmaf(kk, fminf(tf * 1.00001f + 1e-5f, T), rho);
+        const float ax2 = (nd.lo[0] - g2 - cwx) * jx, bx2 = (nd.hi[0] + g2 - cwx) * jx;
+        const float ay2 = (nd.lo[1] - g2 - cwy) * jy, by2 = (nd.hi[1] + g2 - cwy) * jy;
+        const float az2 = (nd.lo[2] - g2 - cwz) * jz, bz2 = (nd.hi[2] + g2 - cwz) * jz;
+        const float tn2 = fmaxf(fmaxf(fminf(ax2, bx2), fminf(ay2, by2)), fmaxf(fminf(az2, bz2), 0.0f));
+        const float tf2 = fminf(fminf(fmaxf(ax2, bx2), fmaxf(ay2, by2)), fminf(fmaxf(az2, bz2), T));
+        return tn2 <= tf2 * 1.00001f + 1e-5f;
+      }, wave_list, WAVE_LEAF_CAP);
+    }
+  }
+  if (n_wl >= 0) {
+    for (int e = 0; e < n_wl; ++e) {
+      const BvhNode nd = load_node(ac, wave_list[e]);
+      if (node_hit(nd)) bvh_leaf(ac, nd, prim_may, on_prim);
+    }
+  } else {
+    bvh_walk(ac, node_hit, prim_may, on_prim);
+  }
   *k_out = bk;
   return best;
 }

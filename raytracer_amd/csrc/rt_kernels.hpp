@@ -80,7 +80,7 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
 
 // Small hierarchies (<= LDS_NODES nodes, 32 KiB) are staged in LDS too: the walk is a chain of
 // dependent loads, LDS latency is several times shorter than L2's.
-constexpr int LDS_NODES = 1016;     // (just under 32 KiB: k_trace's nodes + hit staging then fit four workgroups per CU)
+constexpr int LDS_NODES = 988;      // (k_trace's nodes + hit staging + wave lists then fit four workgroups per CU)
 template <bool LDS_SCENE>
 __device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   Accel a = sc.ac;
@@ -182,8 +182,14 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
   constexpr int CHUNK = LDS_SCENE ? TRACE_CHUNK : TRACE_CHUNK / 2;
   __shared__ HitRec s_hits[CHUNK];
   __shared__ uint32_t s_count, s_base;
+  __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];      // per-wave leaf lists (nearest_accel<true>)
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
+  // wave-level scan for the camera rays only (8x8 pixel tiles: one origin, a thin cone; measured 1.13 -> 0.74 ms on
+  // the synthetic 4K frame).  The deeper levels' waves mix transmitted and reflected rays of many surfaces: their
+  // cones are too wide, and the attempt costs them ~3 %.  RT_DEBUG_STATS=4096: per-lane walks everywhere (A/B).
+  const bool wave_mode = !LDS_SCENE && ac.n_nodes > 0 && ac.n_cut > 0;
+  const bool try_wave = level == 0 && !(fp.debug & 4096u);
   uint32_t count = C->n_rays[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
   const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
@@ -196,10 +202,18 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
       const bool active = slot < count;
       bool hit = false;
       int k = -1; double t = RT_INF;
-      if (active) {
-        RayIn r = load_ray(level, slot, cam, fp.rs, q);
-        t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &ac);
-        hit = k >= 0;
+      if (active || wave_mode) {
+        RayIn r;
+        if (wave_mode) {
+          // all 64 lanes take part in the wave-level scan: the idle lanes of the last wave copy its last ray
+          r = load_ray(level, active ? slot : count - 1, cam, fp.rs, q);
+          t = nearest_accel<true>(P, sc.nS, sc.nP, ac, r.o, r.d, &k, fp.plane_thr, s_wleaves + (threadIdx.x >> 6) * (LDS_SCENE ? 0 : WAVE_LEAF_CAP), try_wave);
+        } else {
+          r = load_ray(level, slot, cam, fp.rs, q);
+          t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &ac);
+        }
+        hit = active && k >= 0;
+        if (active) {
         if (level == 0) {
           // every pixel has exactly one level-0 ray: a plain store initialises the framebuffer
           // (0 + 1*bg == bg exactly); hit pixels are stored by the level-0 shade kernel
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
           }
         } else if (!hit) {
           fb_add(fb, r.lp, r.w.x * sc.bg[0], r.w.y * sc.bg[1], r.w.z * sc.bg[2]);   // :500-502
+        }
         }
       }
       const uint32_t ls = wave_append(&s_count, hit);   // LDS atomic, one per wave

@@ -45,7 +45,7 @@ __device__ __forceinline__ f3 normalize_clamped(f3 a) {   // v / max(|v|, 1e-6)
 constexpr float T_LO = 2e-6f;   // see header: 1e-6 origin shift + 1e-6 hit threshold
 
 constexpr int LEAF_LIST = 20, CAND_LIST = 16;   // per-lane lists of the large-scene walk (entries, in LDS)
-constexpr int WAVE_LEAF_CAP = 64;
+// (WAVE_LEAF_CAP, rt_device.hpp: leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves)
 constexpr int WAVE_REC_CAP = 128;     // records a (wave, light) list holds; more: the lanes test their leaves' bounds themselves     // leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves
 
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>

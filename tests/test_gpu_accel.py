@@ -170,7 +170,7 @@ def test_far_hits_keep_the_culling_conservative():
 
 
 def test_hierarchy_larger_than_the_lds_staging(oracle):
-    """More than 1016 nodes (LDS_NODES): the hierarchy is not staged in LDS, the walks read it from global memory
+    """More than 988 nodes (LDS_NODES): the hierarchy is not staged in LDS, the walks read it from global memory
     (load_node's second branch).  RT_BVH_LEAF=1 gives every record its own leaf, so 1400 records make
     ~1600 nodes."""
     from raytracer_amd.render import render_hip
