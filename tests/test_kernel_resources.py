@@ -23,3 +23,23 @@ def test_headline_kernel_keeps_two_waves_per_simd():
     assert int(occ.group(1)) >= 2, out
     assert spill is None or int(spill.group(1)) == 0, out
     assert int(vgprs.group(1)) <= 256
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+@pytest.mark.parametrize("kernel,header,args,min_occ", [
+    # large-scene shade kernel, 3x3 shadow grid: 2 waves/SIMD (LDS lists + <= 256 VGPRs)
+    ("rt::k_shade_fast<9, false, true, false>", "rt_shade_fast.hpp",
+     "(rt::DevScene, rt::DevCamera, rt::FrameParams, int, rt::RayQueue, rt::RayQueue, const rt::HitRec*, rt::Counters*, float*, int)", 2),
+    # large-scene trace kernel: four workgroups per CU (nodes + hit staging + wave lists <= 40 KiB, <= 128 VGPRs);
+    # the hierarchy walk is a latency chain, 3 -> 4 waves/SIMD was worth 14 %
+    ("rt::k_trace<float, false>", "rt_kernels.hpp",
+     "(rt::DevScene, rt::DevCamera, rt::FrameParams, int, rt::RayQueue, rt::HitRec*, rt::Counters*, float*)", 4),
+])
+def test_large_scene_kernels_keep_their_occupancy(kernel, header, args, min_occ):
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), kernel, header, args],
+                         capture_output=True, text=True, timeout=600).stdout
+    occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", out)
+    spill = re.search(r"VGPRs Spill: (\d+)", out)
+    assert occ, out
+    assert int(occ.group(1)) >= min_occ, out
+    assert spill is None or int(spill.group(1)) == 0, out
