@@ -467,10 +467,13 @@ static int drain(rt_scene* s) {
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & 2))
       fprintf(stderr, "[rt debug] shortcut audit: fully-lit claims wrong %llu, umbra claims wrong %llu, penumbra lanes %llu of %llu\n",
               (unsigned long long)c.dbg[0], (unsigned long long)c.dbg[1], (unsigned long long)c.dbg[2], (unsigned long long)c.dbg[3]);
-    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && c.dbg[0]) {
+    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (c.dbg[0] || c.dbg[1])) {
       const int bits = atoi(getenv("RT_DEBUG_STATS"));
       const double n0 = (double)c.dbg[0];
-      if (bits & 2048)
+      if (bits & 65536)
+        fprintf(stderr, "[rt debug] culling audit: %llu exact (fp64) crossings of records by shadow-segment bundles, %llu bundles with a crossed record that never reached the sample block\n",
+                (unsigned long long)c.dbg[1], (unsigned long long)c.dbg[0]);
+      else if (bits & 2048)
         fprintf(stderr, "[rt debug] k_shade_fast large-scene walk, share of the waves' cycles: find leaves %.3f, record bounds %.3f, sample blocks %.3f\n",
                 c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
       else if (bits & 1024)

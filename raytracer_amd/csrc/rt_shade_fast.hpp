@@ -297,13 +297,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float Lx = (float)lg[0], Ly = (float)lg[1], Lz = (float)lg[2];
             const float ddx = -tl.x, ddy = -tl.y, ddz = -tl.z;                      // p - Lp
             auto fan_may_touch = [&](float cx, float cy, float cz, float r) __attribute__((always_inline)) {
+              if (RT_DBG(fp) & 16384u) return true;
               const float wx = Lx - cx, wy = Ly - cy, wz = Lz - cz;
               const float R0 = r + RL + 4e-5f * (1.0f + fabsf(wx) + fabsf(wy) + fabsf(wz));
               const float qb = fmaf(wz, ddz, fmaf(wy, ddy, wx * ddx)) + RL * R0;
               const float sa = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);                // min of |w + s d|^2 - (R0 - s RL)^2
               const float xx = fmaf(sa, ddx, wx), xy = fmaf(sa, ddy, wy), xz = fmaf(sa, ddz, wz);
               const float wr = fmaf(-sa, RL, R0);
-              return (qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= wr * wr);
+              return bool((qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= wr * wr));
             };
             // node boxes: segment Lp -> p against the box grown by the fan radius (+ fp32 slack), 0 <= s <= 1
             const float gx = fabsf(ddx) > 1e-20f ? raw_rcp(ddx) : 1e30f, gy = fabsf(ddy) > 1e-20f ? raw_rcp(ddy) : 1e30f,
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             unsigned dbg_nodes = 0, dbg_bounds = 0, dbg_cands = 0;
             auto node_hit = [&](const BvhNode& nd) __attribute__((always_inline)) {
               if (RT_DBG(fp)) { ++dbg_nodes; dbg_bounds += nd.count(); }
+              if (RT_DBG(fp) & 32768u) return true;
               const float ax = (nd.lo[0] - grow - Lx) * gx, bx = (nd.hi[0] + grow - Lx) * gx;
               const float ay = (nd.lo[1] - grow - Ly) * gy, by = (nd.hi[1] + grow - Ly) * gy;
               const float az = (nd.lo[2] - grow - Lz) * gz, bz = (nd.hi[2] + grow - Lz) * gz;
@@ -340,6 +342,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             // Lists are bounded: a full leaf list pauses phase 1, a nearly full candidate list pauses phase 2.
             // When the wave has a record list (compact wave: the usual case after the regrouping of
             // rt_sort.hpp), phases 1 and 2 shrink to one bound test per listed record.
+            unsigned audit_crossed = 0;
+            auto exact_crossed = [&](int k) {
+              const Prim& s_ = P[k];
+              bool crossed = false;
+#pragma unroll
+              for (int sidx = 0; sidx < CH; ++sidx) {
+                if (c * CH + sidx >= n_cells) continue;
+                const double ex = dx[sidx], ey = dy[sidx], ez = dz[sidx], mdd = md[sidx];
+                if (k < sc.nS) {
+                  const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
+                  double tt = -(ocx * ex + ocy * ey + ocz * ez);
+                  tt = tt < 0.0 ? 0.0 : (tt > mdd ? mdd : tt);
+                  const double qx = ocx + tt * ex, qy = ocy + tt * ey, qz = ocz + tt * ez;
+                  crossed |= qx * qx + qy * qy + qz * qz < s_.a[4] * (1.0 - 1e-6);
+                } else {
+                  double tn = 0.0, tf = mdd;
+                  const double o3[3] = {p.x, p.y, p.z}, e3[3] = {ex, ey, ez};
+                  for (int ax = 0; ax < 3; ++ax) {
+                    const double inv = 1.0 / e3[ax];
+                    double t0 = (s_.a[ax] - o3[ax]) * inv, t1 = (s_.a[3 + ax] - o3[ax]) * inv;
+                    if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+                    tn = t0 > tn ? t0 : tn; tf = t1 < tf ? t1 : tf;
+                  }
+                  crossed |= tn < tf - 1e-6;
+                }
+              }
+              return crossed;
+            };
             uint32_t* const my_leaf = s_leaf + threadIdx.x;       // entry e at [e * BLOCK]
             uint32_t* const my_cand = s_cand + threadIdx.x;
             const int n_nodes = ac.n_nodes;
@@ -410,6 +440,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
                 if (e < n_cand) {
                   const int k = (int)my_cand[e * BLOCK];
                   if (RT_DBG(fp)) ++dbg_cands;
+                  if ((RT_DBG(fp) & 65536u) && exact_crossed(k)) ++audit_crossed;
                   if (k < sc.nS) do_sphere(P[k]);
                   else if (HAS_BOX) do_box(P[k]);
                 }
@@ -426,6 +457,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (lane == 0) {
                 atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], (unsigned long long)it1);
                 atomicAdd(&C->dbg[2], (unsigned long long)it2); atomicAdd(&C->dbg[3], (unsigned long long)it3);
+              }
+            }
+            if (RT_DBG(fp) & 65536u) {
+              // audit: every record that one of the lane's shadow segments crosses (fp64, exact geometry) must
+              // have reached the lane's sample block — whatever dropped it (wave-level lists, node tests, the
+              // lane's fan test) would not be conservative.  (The fp32 sample block is no judge here: for hits
+              // ~1e3 units away its sphere roots cancel and report spurious crossings.)
+              unsigned n_all = 0; int first_k = -1;
+              for (int k = 0; k < sc.n; ++k) {
+                if (k >= sc.nS && k < sc.nS + sc.nP) continue;
+                if (exact_crossed(k)) { ++n_all; if (first_k < 0) first_k = k; }
+              }
+              if (active) {
+                atomicAdd(&C->dbg[1], (unsigned long long)n_all);
+                if (n_all != audit_crossed && atomicAdd(&C->dbg[0], 1ull) < 6ull)
+                  printf("[audit] %u records crossed, %u of them processed (first crossed: %d): p (%.9g %.9g %.9g) L (%.9g %.9g %.9g) RL %g level %d wave lists %d %d\n",
+                         n_all, audit_crossed, first_k, p.x, p.y, p.z, lg[0], lg[1], lg[2], RL, level, n_wl, n_wr);
               }
             }
             if ((RT_DBG(fp) & 1u) && active) {

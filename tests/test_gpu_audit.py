@@ -32,3 +32,31 @@ def test_shortcut_claims_agree_with_the_sample_loop():
     print(f"audit: {total} (hit, light) pairs, {penumbra} need the sample loop, wrong claims: {wrong_lit} lit, {wrong_umbra} umbra")
     assert wrong_lit == 0 and wrong_umbra == 0
     assert total == 10979324 * 5 and 0 < penumbra < total
+
+
+def _audit_counts(stderr):
+    found = re.findall(r"culling audit: (\d+) exact \(fp64\) crossings of records by shadow-segment bundles, (\d+) bundles", stderr)
+    return sum(int(a) for a, _ in found), sum(int(b) for _, b in found), len(found)
+
+
+def test_large_scene_culling_never_drops_a_crossed_record():
+    """k_shade_fast's large-scene path drops records at four places (wave-level leaf list, wave-level record
+    list, per-lane node tests, per-lane fan test).  The audit build checks in fp64, for every (hit, light),
+    that every record crossed by one of the lane's shadow segments reached the lane's sample block: on the
+    synthetic 4609-primitive scene and on randomised scenes with lights inside the slab, huge light radii,
+    cameras among the objects and floor hits thousands of units away (tools/stress_accel.py)."""
+    if not os.path.exists(DEBUG_LIB):
+        pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
+    env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS="65536")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "synth4k", "--scale", "4", "--frames", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    crossings, dropped, frames = _audit_counts(p.stderr)
+    print(f"synthetic scene 960x540: {crossings} exact crossings over {frames} frames, {dropped} dropped")
+    assert frames >= 1 and crossings > 1000000 and dropped == 0, p.stderr[-2000:]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_accel.py"), "100", "45"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    crossings, dropped, frames = _audit_counts(p.stderr)
+    print(f"45 randomised large scenes: {crossings} exact crossings over {frames} frames, {dropped} dropped")
+    assert frames >= 45 and crossings > 10000 and dropped == 0, p.stderr[-2000:]
