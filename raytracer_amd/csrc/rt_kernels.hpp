@@ -17,6 +17,16 @@ namespace rt {
 
 // Audit / statistics code in the kernels exists only in the debug build (make debug ->
 // librt_hip_debug.so, selected with RT_HIP_LIBRARY); in the product library RT_DBG() is a constant 0.
+// Bits of RT_DEBUG_STATS (FrameParams::debug), fp32 kernels:
+//       1  event counts (k_shade_ls: (wave, light) pairs; k_shade_fast large scenes: node tests / records per walk)
+//       2  shortcuts off, their claims audited against the sample loop (k_shade_ls, k_shade_fast LDS scenes)
+//       4  k_shade_ls: force the exact own-surface (LO) path        8  fan_cull: every record is a candidate
+//   16/32  large-scene walk: skip the record-bound / sample-block phases (timing experiments, wrong images)
+//      64  no wave-level leaf list   128  statistics of the wave-level lists   256  no cone-tapered second node test
+//     512  no wave-level record list   1024 / 2048  wave-level steps / cycles per phase
+//    4096  k_trace: per-lane walks for the camera rays too (this bit is honoured by the product library as well)
+//   16384 / 32768  the lane's fan test / node test always pass (bisecting a culling problem)
+//   65536  exact audit of the large-scene culling (fp64: every crossed record must reach the sample block)
 #ifdef RT_DEBUG_KERNEL
 #define RT_DBG(fp) ((fp).debug)
 #else
