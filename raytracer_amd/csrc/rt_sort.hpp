@@ -11,14 +11,14 @@
 //
 // Three launches: per-block histograms in LDS -> table[bin][block] (+ per-bin totals, one global atomic
 // per non-empty (block, bin)), exclusive scan of the table in bin-major order = final order (one block
-// per 32 bins; its base is the sum of the totals of the bins before), scatter with LDS cursors.
+// per 16 bins; its base is the sum of the totals of the bins before), scatter with LDS cursors.
 #pragma once
 #include "rt_kernels.hpp"
 
 namespace rt {
 
 constexpr int SORT_BINS = 4096;       // grid cells (12 bits split over the axes by the host)
-constexpr int SORT_BLOCKS = 128;      // blocks of the count / scatter launches; block b owns one contiguous range
+constexpr int SORT_BLOCKS = 256;      // blocks of the count / scatter launches; block b owns one contiguous range
 constexpr int SORT_THREADS = 1024;
 
 struct SortGrid {                     // cell of p: clamp((p - lo) * inv, 0, n - 1) per axis, index (x * ny + y) * nz + z
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count(DevCamera cam, Fram
 // Exclusive scan of table[SORT_BINS * SORT_BLOCKS] in place, bin-major.  Block g owns SCAN_BINS bins
 // (SCAN_BINS * SORT_BLOCKS consecutive entries, one per thread-quad); its base is the sum of bin_total over
 // the bins before its first one.
-constexpr int SCAN_BINS = 32;
+constexpr int SCAN_BINS = 16;
 constexpr int SCAN_THREADS = 1024;
 __global__ __launch_bounds__(SCAN_THREADS) void k_sort_scan(uint32_t* __restrict__ table, const uint32_t* __restrict__ bin_total) {
   constexpr int PER = SCAN_BINS * SORT_BLOCKS / SCAN_THREADS;        // consecutive entries per thread
