@@ -383,7 +383,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int k = 0; k < 3; ++k) s->ds.scene_m += std::max(std::fabs(accel_lo[k]), std::fabs(accel_hi[k]));
   if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
   if (!nodes.empty() && !(getenv("RT_SORT_HITS") && atoi(getenv("RT_SORT_HITS")) == 0)) {
-    // grid over the hierarchy's root box: 12 bits, each given to the axis whose cells are largest
+    // grid over the hierarchy's bounds: 13 bits, each given to the axis whose cells are largest
     s->sort_hits = true;
     auto make_grid = [&](SortGrid& g, int total_bits) {
       float ext[3]; int bits[3] = {0, 0, 0};
@@ -396,7 +396,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       for (int k = 0; k < 3; ++k) { g.n[k] = 1 << bits[k]; g.inv[k] = (float)g.n[k] / ext[k]; }
       g.pad = 0;
     };
-    make_grid(s->sort_grid, 12);
+    make_grid(s->sort_grid, 13);
   }
   *out = s;
   return RT_OK;
