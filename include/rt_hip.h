@@ -133,6 +133,26 @@ int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part, int32_t n_
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, void* out, int out_is_device,
               rt_stats* stats);
 
+/*
+ * rt_render for callers that cannot allocate.  No counterpart in the reference: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc — rt_render grows a per-scene workspace on
+ * demand, this variant never does.  Same kernels and results as rt_render with out_is_device = 1; everything a
+ * frame needs beyond its input and output (counters, hit queue, two bounce-ray queues, a framebuffer when the
+ * output is converted) is carved out of ONE static device array of RT_STATIC_SCRATCH_MIB MiB that each GPU the
+ * library runs on holds until the process ends.  The call makes no hipMalloc / hipFree / hipHostMalloc and creates
+ * no events (the scene handle and its pinned counter block were allocated by rt_scene_create).
+ * Limits: rows*width <= RT_STATIC_MAX_PIXELS per call (RT_ERR_INVALID beyond; render larger frames as row sets);
+ * pixel-keyed jitter; no RT_FLAG_TIMING; `out` is device memory.  The bounce queues take what the array has left
+ * (>= 1.3 rays per pixel and level at the maximum size, more for smaller row sets); a frame that needs more fails
+ * with RT_ERR_QUEUE_OVERFLOW — nothing is written out of bounds, and nothing is retried.  Blocks until the frame
+ * is complete; with RT_FLAG_ASYNC (stats must be NULL) it only enqueues on the scene's stream.
+ * All calls on one GPU share that GPU's array: calls of one process are serialised by the library, but an
+ * RT_FLAG_ASYNC frame still in flight when the next call on the same GPU starts races with it (sync in between).
+ */
+#define RT_STATIC_SCRATCH_MIB 32
+#define RT_STATIC_MAX_PIXELS 131072
+int rt_render_static(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, void* out_device, rt_stats* stats);
+
 /* Test/utility exports (host pointers, fp64), one per reference helper:
  * rt_nearest_hit          == find_nearest_intersection_batch (ray_tracer.py:112-127)
  * rt_shadow_transmission  == compute_shadow_transmission_batch (ray_tracer.py:247-293)

@@ -54,6 +54,8 @@ extern "C" int rt_device_count(int* count) {
   return RT_OK;
 }
 
+static int static_scratch_for(int device, unsigned char** out);   // rt_render_static, below
+
 // --------------------------------------------------------------- culling hierarchy (host) ------
 // Built once per scene for scenes that do not fit the LDS-staged brute-force kernels (n > LDS_PRIMS):
 // spheres and boxes are ordered by recursive median splits of their centres inside their type range
@@ -207,6 +209,19 @@ struct PendingFrame {
   int64_t s_level_rays[MAX_LEVELS] = {0}, s_level_hits[MAX_LEVELS] = {0};
 };
 
+// Device buffers one frame's kernels work in: the scene's own (grown on demand, ensure_workspace) or a
+// carve-up of the static scratch array (rt_render_static).
+struct WorkBufs {
+  void* fb = nullptr;                 // pixels*3 doubles (also used as float)
+  HitRec* hits = nullptr;
+  HitRec* hits_sorted = nullptr; uint16_t* sort_keys = nullptr; uint32_t* sort_table = nullptr;   // sort == true only
+  double* qbuf[2] = {nullptr, nullptr};   // 9*cap_queue doubles each
+  uint32_t* qpix[2] = {nullptr, nullptr};
+  Counters* counters = nullptr;
+  size_t cap_queue = 0;
+  bool sort = false;                  // regroup the hits of level >= 1 by grid cell (large scenes)
+};
+
 struct rt_scene {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -233,6 +248,10 @@ struct rt_scene {
   std::vector<Counters*> h_slots;           // pinned
   std::deque<PendingFrame> pending;
   std::vector<hipEvent_t> event_pool;
+  // rt_render_static: this device's copy of the static scratch array (hipGetSymbolAddress at scene creation)
+  // and a pinned counters block, so that the call itself allocates nothing
+  unsigned char* static_scratch = nullptr;
+  Counters* h_static = nullptr;
   std::mutex mu;
 };
 
@@ -357,6 +376,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   HIPCHK_S(hipMalloc(&s->d_mats, mats.size() * sizeof(double)));
   HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(double)));
   HIPCHK_S(hipMalloc(&s->d_counters, sizeof(Counters)));
+  HIPCHK_S(hipHostMalloc(&s->h_static, sizeof(Counters)));
+  { int rc_ = static_scratch_for(device, &s->static_scratch); if (rc_ != RT_OK) return bail(rc_); }
   if (!prims.empty()) HIPCHK_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
   HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -415,6 +436,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_cut) hipFree(s->d_cut);
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
+  if (s->h_static) hipHostFree(s->h_static);
   for (hipEvent_t e : s->event_pool) hipEventDestroy(e);
   for (PendingFrame& pf : s->pending) {   // frames never synced: their rt_stats are not written
     for (EventPair& ep : pf.events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
@@ -443,6 +465,33 @@ extern "C" int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part,
   if (tail && (full_blocks % n_parts) == part) r += tail;
   *rows = r;
   return RT_OK;
+}
+
+// Fold a finished frame's device counters (and event timings) into the caller's rt_stats.
+static void fill_stats(PendingFrame& pf, const Counters& c, rt_stats* out) {
+  rt_stats st; std::memset(&st, 0, sizeof st);
+  st.levels = pf.levels;
+  if (pf.stream) {
+    st.rays = pf.s_rays; st.hits = pf.s_hits; st.batches = pf.s_batches;
+    for (int l = 0; l < pf.levels; ++l) { st.level_rays[l] = pf.s_level_rays[l]; st.level_hits[l] = pf.s_level_hits[l]; }
+  }
+  for (int l = 0; l < pf.levels && !pf.stream; ++l) {
+    st.level_rays[l] = c.n_rays[l]; st.level_hits[l] = c.n_hits[l];
+    st.rays += c.n_rays[l]; st.hits += c.n_hits[l];
+    if (c.n_rays[l]) st.batches++;
+  }
+  st.shadow_rays = st.hits * (int64_t)pf.n_lights * pf.n_cells;
+  st.segments = pf.precision == RT_FP64 ? (pf.stream ? pf.s_queries : (int64_t)c.queries) - st.shadow_rays : -1;
+  if (pf.timing && !pf.events.empty()) {
+    for (EventPair& ep : pf.events) {
+      float ms = 0; hipEventElapsedTime(&ms, ep.a, ep.b);
+      if (ep.kind == 0) { st.trace_ms += ms; st.trace_launches++; }
+      else if (ep.kind == 1) { st.shade_ms += ms; st.shade_launches++; }
+      else st.other_ms += ms;
+    }
+    hipEventElapsedTime(&st.total_ms, pf.events.front().a, pf.events.back().b);
+  }
+  *out = st;
 }
 
 // Finish every pending frame of a scene: wait, fold counters/events into the callers' rt_stats.
@@ -486,31 +535,7 @@ static int drain(rt_scene* s) {
         fprintf(stderr, "[rt debug] k_shade_fast hierarchy walks (hit, light): %llu; per walk: %.1f nodes tested (holding %.1f record bounds), %.2f records processed\n",
                 (unsigned long long)c.dbg[0], c.dbg[1] / n0, c.dbg[2] / n0, c.dbg[3] / n0);
     }
-    if (pf.user) {
-      rt_stats st; std::memset(&st, 0, sizeof st);
-      st.levels = pf.levels;
-      if (pf.stream) {
-        st.rays = pf.s_rays; st.hits = pf.s_hits; st.batches = pf.s_batches;
-        for (int l = 0; l < pf.levels; ++l) { st.level_rays[l] = pf.s_level_rays[l]; st.level_hits[l] = pf.s_level_hits[l]; }
-      }
-      for (int l = 0; l < pf.levels && !pf.stream; ++l) {
-        st.level_rays[l] = c.n_rays[l]; st.level_hits[l] = c.n_hits[l];
-        st.rays += c.n_rays[l]; st.hits += c.n_hits[l];
-        if (c.n_rays[l]) st.batches++;
-      }
-      st.shadow_rays = st.hits * (int64_t)pf.n_lights * pf.n_cells;
-      st.segments = pf.precision == RT_FP64 ? (pf.stream ? pf.s_queries : (int64_t)c.queries) - st.shadow_rays : -1;
-      if (pf.timing && !pf.events.empty()) {
-        for (EventPair& ep : pf.events) {
-          float ms = 0; hipEventElapsedTime(&ms, ep.a, ep.b);
-          if (ep.kind == 0) { st.trace_ms += ms; st.trace_launches++; }
-          else if (ep.kind == 1) { st.shade_ms += ms; st.shade_launches++; }
-          else st.other_ms += ms;
-        }
-        hipEventElapsedTime(&st.total_ms, pf.events.front().a, pf.events.back().b);
-      }
-      *pf.user = st;
-    }
+    if (pf.user) fill_stats(pf, c, pf.user);
     for (EventPair& ep : pf.events) { s->event_pool.push_back(ep.a); s->event_pool.push_back(ep.b); }
     s->h_slots.push_back(pf.h_counters);
   }
@@ -557,11 +582,20 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
   return RT_OK;
 }
 
-static RayQueue make_queue(rt_scene* s, int which) {
-  RayQueue q; double* b = s->d_qbuf[which]; size_t c = s->cap_queue;
+static RayQueue make_queue(const WorkBufs& wb, int which) {
+  RayQueue q; double* b = wb.qbuf[which]; size_t c = wb.cap_queue;
   q.ox = b; q.oy = b + c; q.oz = b + 2 * c; q.dx = b + 3 * c; q.dy = b + 4 * c; q.dz = b + 5 * c;
-  q.wx = b + 6 * c; q.wy = b + 7 * c; q.wz = b + 8 * c; q.pix = s->d_qpix[which];
+  q.wx = b + 6 * c; q.wy = b + 7 * c; q.wz = b + 8 * c; q.pix = wb.qpix[which];
   return q;
+}
+
+// The scene's own workspace as the buffers of a frame.
+static WorkBufs own_bufs(rt_scene* s) {
+  WorkBufs wb;
+  wb.fb = s->d_fb; wb.hits = s->d_hits; wb.hits_sorted = s->d_hits_sorted; wb.sort_keys = s->d_sort_keys;
+  wb.sort_table = s->d_sort_table; wb.counters = s->d_counters; wb.cap_queue = s->cap_queue; wb.sort = s->sort_hits;
+  for (int i = 0; i < 2; ++i) { wb.qbuf[i] = s->d_qbuf[i]; wb.qpix[i] = s->d_qpix[i]; }
+  return wb;
 }
 
 static DevCamera to_dev_camera(const rt_camera* c) {
@@ -585,13 +619,13 @@ struct Timed {   // RAII-ish helper: bracket one launch with events when timing 
 };
 
 template <typename FB>
-static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp, const rt_frame* fr, FB* fb,
-                        PendingFrame* pf) {
+static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, const FrameParams& fp, const rt_frame* fr,
+                        FB* fb, PendingFrame* pf) {
   const bool lds = s->ds.n <= LDS_PRIMS;
   const int grid = s->num_cu * 8;
-  RayQueue q[2] = {make_queue(s, 0), make_queue(s, 1)};
+  RayQueue q[2] = {make_queue(wb, 0), make_queue(wb, 1)};
   const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
-  { Timed t(s, pf, 2); hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(256), 0, s->stream, s->d_counters, P); }
+  { Timed t(s, pf, 2); hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(256), 0, s->stream, wb.counters, P); }
   for (int level = 0; level <= fp.max_depth; ++level) {
     RayQueue cur = q[level & 1], nxt = q[(level + 1) & 1];
     int tgrid = grid;       // trace: one workgroup per TRACE_CHUNK rays, grid-stride beyond that
@@ -604,38 +638,51 @@ static int launch_frame(rt_scene* s, const DevCamera& cam, const FrameParams& fp
     if (sgrid < 1) sgrid = 1;
     {
       Timed t(s, pf, 0);
-      if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
-      else hipLaunchKernelGGL((k_trace<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, s->d_hits, s->d_counters, fb);
+      if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
+      else hipLaunchKernelGGL((k_trace<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
     }
-    const HitRec* level_hits = s->d_hits;
-    if (s->sort_hits && level >= 1) {
+    const HitRec* level_hits = wb.hits;
+    if (wb.sort && level >= 1) {
       Timed t(s, pf, 2);
-      uint32_t* bin_total = s->d_sort_table + (size_t)SORT_BINS * SORT_BLOCKS;
+      uint32_t* bin_total = wb.sort_table + (size_t)SORT_BINS * SORT_BLOCKS;
       hipMemsetAsync(bin_total, 0, SORT_BINS * sizeof(uint32_t), s->stream);
-      hipLaunchKernelGGL(k_sort_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, cam, fp, level, cur, s->d_hits,
-                         s->d_counters, s->sort_grid, s->d_sort_keys, s->d_sort_table, bin_total);
-      hipLaunchKernelGGL(k_sort_scan, dim3(SORT_BINS / SCAN_BINS), dim3(SCAN_THREADS), 0, s->stream, s->d_sort_table, bin_total);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, fp, level, s->d_hits, s->d_counters,
-                         s->d_sort_keys, s->d_sort_table, s->d_hits_sorted);
-      level_hits = s->d_hits_sorted;
+      hipLaunchKernelGGL(k_sort_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, cam, fp, level, cur, wb.hits,
+                         wb.counters, s->sort_grid, wb.sort_keys, wb.sort_table, bin_total);
+      hipLaunchKernelGGL(k_sort_scan, dim3(SORT_BINS / SCAN_BINS), dim3(SCAN_THREADS), 0, s->stream, wb.sort_table, bin_total);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, s->stream, fp, level, wb.hits, wb.counters,
+                         wb.sort_keys, wb.sort_table, wb.hits_sorted);
+      level_hits = wb.hits_sorted;
     }
     {
       Timed t(s, pf, 1);
       if (fr->precision == RT_FP64) {
-        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, s->d_counters, fb);
-        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, s->d_counters, fb);
+        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, sgrid, s->stream);
         if (!done)
-          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, s->d_counters, (float*)fb, sgrid, s->stream);
+          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, sgrid, s->stream);
       }
     }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return RT_OK;
+}
+
+// Framebuffer -> requested output format (k_convert), on the scene's stream.
+static void launch_convert(rt_scene* s, PendingFrame* pf, const void* fb, bool fb_is_double, int out_format, void* dst, size_t nval) {
+  Timed t(s, pf, 2);
+  const int cg = (int)std::min<size_t>((nval + BLOCK - 1) / BLOCK, (size_t)s->num_cu * 16);
+  if (fb_is_double) {
+    if (out_format == RT_OUT_F32) hipLaunchKernelGGL((k_convert<double, float>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (float*)dst, nval);
+    else hipLaunchKernelGGL((k_convert<double, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (unsigned char*)dst, nval);
+  } else {
+    if (out_format == RT_OUT_F64) hipLaunchKernelGGL((k_convert<float, double>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (double*)dst, nval);
+    else hipLaunchKernelGGL((k_convert<float, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (unsigned char*)dst, nval);
+  }
 }
 
 // ------------------------------------------------- numpy-stream jitter (rt_stream.hpp) ---------
@@ -804,8 +851,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   return rc;
 }
 
-static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
-                         rt_stats* stats) {
+// Argument checks shared by rt_render and rt_render_static; *rows = rows of the frame's row set.
+static int validate_frame(const rt_frame* fr, int out_is_device, int32_t* rows) {
   if (fr->width <= 0 || fr->height <= 0) return fail(RT_ERR_INVALID, "rt_render: bad image size %dx%d", fr->width, fr->height);
   if (fr->block_rows <= 0) return fail(RT_ERR_INVALID, "rt_render: block_rows must be >= 1");
   if (fr->max_depth < 0 || fr->max_depth + 1 > MAX_LEVELS) return fail(RT_ERR_INVALID, "rt_render: max_depth %d outside [0,%d]", fr->max_depth, MAX_LEVELS - 1);
@@ -819,8 +866,26 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if ((fr->flags & RT_FLAG_SEQUENTIAL) && fr->jitter_mode != RT_JITTER_PIXEL_KEYED)
     return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_SEQUENTIAL needs pixel-keyed jitter (the scalar stream order is per-pixel depth-first)");
   if ((fr->flags & RT_FLAG_ASYNC) && !out_is_device) return fail(RT_ERR_INVALID, "rt_render: RT_FLAG_ASYNC needs a device output buffer");
+  return rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, rows);
+}
+
+static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queue) {
+  FrameParams fp;
+  fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
+  fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
+  // 8x8 pixel tiles per wave at level 0; the numpy-stream mode needs hits in ascending pixel order
+  fp.rs.tiled = (fr->jitter_mode == RT_JITTER_PIXEL_KEYED && !getenv("RT_NO_TILES")) ? 1 : 0; fp.rs.pad = 0;
+  fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)cap_queue;
+  fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
+  fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
+  fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
+  return fp;
+}
+
+static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
+                         rt_stats* stats) {
   int32_t rows = 0;
-  int rc = rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, &rows);
+  int rc = validate_frame(fr, out_is_device, &rows);
   if (rc != RT_OK) return rc;
 
   HIPCHK(hipSetDevice(s->device));
@@ -842,41 +907,113 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (s->h_slots.empty()) { Counters* h = nullptr; HIPCHK(hipHostMalloc(&h, sizeof(Counters))); s->h_slots.push_back(h); }
   pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
 
-  FrameParams fp;
-  fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
-  fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
-  // 8x8 pixel tiles per wave at level 0; the numpy-stream mode needs hits in ascending pixel order
-  fp.rs.tiled = (fr->jitter_mode == RT_JITTER_PIXEL_KEYED && !getenv("RT_NO_TILES")) ? 1 : 0; fp.rs.pad = 0;
-  fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)s->cap_queue;
-  fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
-  fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
-  fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
+  const FrameParams fp = make_params(fr, rows, s->cap_queue);
   DevCamera cam = to_dev_camera(camera);
 
   void* fb = direct ? out : s->d_fb;
   if (fr->jitter_mode == RT_JITTER_NUMPY_STREAM) rc = render_stream(s, cam, fp, (double*)fb, &pf);
-  else rc = fb_is_double ? launch_frame<double>(s, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, cam, fp, fr, (float*)fb, &pf);
+  else {
+    const WorkBufs wb = own_bufs(s);
+    rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, fr, (float*)fb, &pf);
+  }
   if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
 
   if (!direct) {
     void* dst = out_is_device ? out : (native ? nullptr : s->d_out);
-    if (!native) {
-      Timed t(s, &pf, 2);
-      const int cg = (int)std::min<size_t>((nval + BLOCK - 1) / BLOCK, (size_t)s->num_cu * 16);
-      if (fb_is_double) {
-        if (fr->out_format == RT_OUT_F32) hipLaunchKernelGGL((k_convert<double, float>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (float*)dst, nval);
-        else hipLaunchKernelGGL((k_convert<double, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const double*)fb, (unsigned char*)dst, nval);
-      } else {
-        if (fr->out_format == RT_OUT_F64) hipLaunchKernelGGL((k_convert<float, double>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (double*)dst, nval);
-        else hipLaunchKernelGGL((k_convert<float, unsigned char>), dim3(cg), dim3(BLOCK), 0, s->stream, (const float*)fb, (unsigned char*)dst, nval);
-      }
-    }
+    if (!native) launch_convert(s, &pf, fb, fb_is_double, fr->out_format, dst, nval);
     if (!out_is_device) HIPCHK(hipMemcpyAsync(out, native ? fb : s->d_out, nval * esz, hipMemcpyDeviceToHost, s->stream));
   }
   HIPCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
   s->pending.push_back(std::move(pf));
   if (fr->flags & RT_FLAG_ASYNC) return RT_OK;
   return drain(s);
+}
+
+// ------------------------------------------------------ rt_render_static (allocates nothing) ---
+// The buffers a frame needs beyond its input and output (counters, framebuffer for converted output, hit queue,
+// two ray queues) are carved out of ONE file-scope device array instead of the scene's grown-on-demand
+// workspace, so the call makes no hipMalloc / hipFree / hipHostMalloc / event creation: usable under HIP graph
+// capture, in serving loops and in harnesses that forbid allocation.  Each GPU holds its own copy of the array
+// at its own address (the name below is only a host-side stand-in): the address is taken once per device with
+// hipGetSymbolAddress, with that device current, when a scene is created there (static_scratch_for).
+static __device__ __align__(256) unsigned char scratch[(size_t)RT_STATIC_SCRATCH_MIB << 20];
+constexpr size_t STATIC_BYTES = (size_t)RT_STATIC_SCRATCH_MIB << 20;
+constexpr int STATIC_MAX_DEVICES = 64;
+static unsigned char* g_static_ptr[STATIC_MAX_DEVICES];     // per device; nullptr = not taken yet
+static std::mutex g_static_mu;                              // guards g_static_ptr
+static std::mutex g_static_call_mu[STATIC_MAX_DEVICES];     // calls on one GPU share its array: serialised per process
+
+// Address of `device`'s copy of the scratch array.  The caller has made `device` current.
+static int static_scratch_for(int device, unsigned char** out) {
+  if (device < 0 || device >= STATIC_MAX_DEVICES) return fail(RT_ERR_INVALID, "device %d beyond the %d the static scratch table holds", device, STATIC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[device]) {
+    unsigned char* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+    g_static_ptr[device] = ptr;
+  }
+  *out = g_static_ptr[device];
+  return RT_OK;
+}
+
+extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out_device, rt_stats* stats) {
+  if (!s || !camera || !fr || !out_device) return fail(RT_ERR_INVALID, "rt_render_static: null pointer");
+  std::lock_guard<std::mutex> lk(s->mu);
+  int32_t rows = 0;
+  int rc = validate_frame(fr, 1, &rows);
+  if (rc != RT_OK) return rc;
+  if (fr->jitter_mode != RT_JITTER_PIXEL_KEYED) return fail(RT_ERR_INVALID, "rt_render_static: pixel-keyed jitter only (the numpy-stream mode allocates per batch)");
+  if (fr->flags & RT_FLAG_TIMING) return fail(RT_ERR_INVALID, "rt_render_static: RT_FLAG_TIMING creates events; use rt_render for timing");
+  if ((fr->flags & RT_FLAG_ASYNC) && stats) return fail(RT_ERR_INVALID, "rt_render_static: RT_FLAG_ASYNC needs stats == NULL (counters are read back by blocking calls only)");
+  const size_t pixels = (size_t)rows * fr->width, nval = pixels * 3;
+  if (pixels > (size_t)RT_STATIC_MAX_PIXELS)
+    return fail(RT_ERR_INVALID, "rt_render_static: %zu pixels in the row set, the static scratch serves at most %d (render in parts or use rt_render)",
+                pixels, RT_STATIC_MAX_PIXELS);
+  if (pixels == 0) { if (stats) std::memset(stats, 0, sizeof *stats); return RT_OK; }
+  if (!s->static_scratch || !s->h_static) return fail(RT_ERR_INVALID, "rt_render_static: scene has no static scratch (creation failed to take its address)");
+  HIPCHK(hipSetDevice(s->device));
+  std::lock_guard<std::mutex> dev_lk(g_static_call_mu[s->device]);
+
+  // carve-up: counters | framebuffer | hit queue | ray queue 0 | ray queue 1 | pixel indices 0 | 1
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  unsigned char* base = s->static_scratch;
+  size_t off = 0;
+  WorkBufs wb;
+  wb.counters = (Counters*)(base + off); off += up256(sizeof(Counters));
+  wb.fb = base + off; off += up256(pixels * 3 * sizeof(double));
+  const size_t per_slot = sizeof(HitRec) + 2 * (9 * sizeof(double) + sizeof(uint32_t));
+  const size_t cap = ((STATIC_BYTES - off) / per_slot) & ~(size_t)63;
+  wb.hits = (HitRec*)(base + off); off += cap * sizeof(HitRec);
+  for (int i = 0; i < 2; ++i) { wb.qbuf[i] = (double*)(base + off); off += cap * 9 * sizeof(double); }
+  for (int i = 0; i < 2; ++i) { wb.qpix[i] = (uint32_t*)(base + off); off += cap * sizeof(uint32_t); }
+  wb.cap_queue = cap; wb.sort = false;      // (regrouping is a scheduling step only; its buffers are not carved)
+  if (off > STATIC_BYTES || cap < pixels) return fail(RT_ERR_INVALID, "rt_render_static: internal carve-up error");
+
+  PendingFrame pf;
+  pf.user = stats; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
+  pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
+  pf.precision = fr->precision; pf.timing = false;
+  const FrameParams fp = make_params(fr, rows, cap);
+  const DevCamera cam = to_dev_camera(camera);
+  const bool fb_is_double = fr->precision == RT_FP64;
+  const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
+  void* fb = native ? out_device : wb.fb;
+  rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, fr, (float*)fb, &pf);
+  if (rc != RT_OK) return rc;
+  if (!native) launch_convert(s, &pf, fb, fb_is_double, fr->out_format, out_device, nval);
+  if (fr->flags & RT_FLAG_ASYNC) return RT_OK;
+  HIPCHK(hipMemcpyAsync(s->h_static, wb.counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  const Counters& c = *s->h_static;
+  if (c.overflow) {
+    size_t need = 0;
+    for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
+    return fail(RT_ERR_QUEUE_OVERFLOW, "rt_render_static: a level holds >= %zu rays, the static queues hold %zu for a row set of %zu pixels "
+                "(this entry point cannot grow them: use rt_render, or render fewer rows per call)", need, cap, pixels);
+  }
+  if (stats) fill_stats(pf, c, stats);
+  return RT_OK;
 }
 
 // ------------------------------------------------------------------- utility exports -----------

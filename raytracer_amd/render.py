@@ -71,9 +71,10 @@ class GpuScene:
 
     # -- the hot path -------------------------------------------------------------------------
     def render(self, camera, width, height, n_shadow, max_depth, *, precision="fp64", jitter=None,
-               block_rows=1, part=0, n_parts=1, out_format=None, out_ptr=None, flags=0, stats=None):
+               block_rows=1, part=0, n_parts=1, out_format=None, out_ptr=None, flags=0, stats=None, static=False):
         """Render a row set.  With `out_ptr` (a device pointer, e.g. torch_tensor.data_ptr()) the
-        result stays on the GPU; otherwise a NumPy array (rows, width, 3) is returned."""
+        result stays on the GPU; otherwise a NumPy array (rows, width, 3) is returned.
+        static=True (needs out_ptr) goes through rt_render_static, the entry point that allocates nothing."""
         jit = as_jitter(jitter)
         if camera.forward is None:
             camera.setup(width / height)
@@ -88,10 +89,19 @@ class GpuScene:
         fr = _lib.Frame(int(width), int(height), int(block_rows), int(part), int(n_parts), int(n_shadow),
                         int(max_depth), prec, int(jit.mode), jit.seed & 0xFFFFFFFF, fmt, int(flags))
         st = stats if stats is not None else _lib.Stats()
+        if static:
+            if out_ptr is None:
+                raise ValueError("static=True renders into device memory: pass out_ptr")
+            _lib.check(self._lib.rt_render_static(self._h, C.byref(cam), C.byref(fr), C.c_void_p(out_ptr),
+                                                  None if (flags & _lib.RT_FLAG_ASYNC) else C.byref(st)))
+            self.last_stats = st.as_dict()
+            return None
         if out_ptr is not None:
             if flags & _lib.RT_FLAG_ASYNC:
                 self._keepalive.append(st)
             _lib.check(self._lib.rt_render(self._h, C.byref(cam), C.byref(fr), C.c_void_p(out_ptr), 1, C.byref(st)))
+            if not (flags & _lib.RT_FLAG_ASYNC):
+                self.last_stats = st.as_dict()
             return None
         rows = len(rows_in_part(height, block_rows, part, n_parts))
         out = np.empty((rows, width, 3), dtype=dtype)
