@@ -42,11 +42,15 @@ typedef enum rt_jitter_mode {
 typedef enum rt_out_format { RT_OUT_F64 = 0, RT_OUT_F32 = 1, RT_OUT_U8 = 2 } rt_out_format;
 enum { RT_FLAG_ASYNC = 1,  /* device output only: return after enqueueing; call rt_sync() */
        RT_FLAG_TIMING = 2, /* bracket every kernel with HIP events, fill the *_ms stats fields */
-       RT_FLAG_SEQUENTIAL = 4 /* semantics of the reference's per-pixel recursive render() (ray_tracer.py:296-434)
+       RT_FLAG_SEQUENTIAL = 4, /* semantics of the reference's per-pixel recursive render() (ray_tracer.py:296-434)
                                  instead of render_vectorized: plane accepts t == 1e-6 (infinite_plane.py:20), unbounded
                                  shadow walk returning 0 below 1e-6 (:303-320), lights with intensity factor < 1e-6 skipped
                                  (:347-348), specular only for r.v > 0 (:356), background*transparency where the transmitted
-                                 ray is not traced (:370-377).  Pixel-keyed jitter only; fp32 applies the last item only. */ };
+                                 ray is not traced (:370-377).  Pixel-keyed jitter only; fp32 applies the last item only. */
+       RT_FLAG_BRUTE_FORCE = 8 /* fp32 shade kernels test EVERY surface for EVERY shadow sample, like the reference's loop over
+                                 all surfaces (ray_tracer.py:119-125): no candidate sets, no fully-lit / umbra shortcuts, no
+                                 culling hierarchy.  Same image; exists so that the roofline fraction can be measured on a run
+                                 that executes the algorithmic flop model's work (bench.py, roofline.brute_force). */ };
 
 /*
  * Scene description, in scene-file (list) order — the order defines nearest-hit tie-breaking
@@ -102,6 +106,8 @@ typedef struct rt_stats {
   float trace_ms, shade_ms, other_ms;   /* RT_FLAG_TIMING: summed kernel durations (HIP events) */
   int32_t trace_launches, shade_launches;
   float total_ms;                        /* RT_FLAG_TIMING: first kernel start -> last kernel end */
+  int64_t retested;     /* fp32 mode: (hit, light) pairs whose shadow term was re-evaluated in fp64 because one of their
+                           hit / miss decisions lay within the fp32 error bound (0 in fp64 mode) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

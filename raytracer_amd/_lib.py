@@ -12,7 +12,7 @@ RT_OK = 0
 RT_ERR_QUEUE_OVERFLOW = -4
 RT_FP64, RT_FP32 = 0, 1
 RT_OUT_F64, RT_OUT_F32, RT_OUT_U8 = 0, 1, 2
-RT_FLAG_ASYNC, RT_FLAG_TIMING, RT_FLAG_SEQUENTIAL = 1, 2, 4
+RT_FLAG_ASYNC, RT_FLAG_TIMING, RT_FLAG_SEQUENTIAL, RT_FLAG_BRUTE_FORCE = 1, 2, 4, 8
 RT_MAX_LEVELS = 32
 RT_STATIC_MAX_PIXELS = 131072
 
@@ -44,12 +44,13 @@ class Stats(C.Structure):
                 ("batches", C.c_int32), ("levels", C.c_int32),
                 ("level_rays", C.c_int64 * RT_MAX_LEVELS), ("level_hits", C.c_int64 * RT_MAX_LEVELS),
                 ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("other_ms", C.c_float),
-                ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("total_ms", C.c_float)]
+                ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("total_ms", C.c_float),
+                ("retested", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("rays", "hits", "shadow_rays", "segments", "batches", "levels",
                                            "trace_ms", "shade_ms", "other_ms", "trace_launches",
-                                           "shade_launches", "total_ms")}
+                                           "shade_launches", "total_ms", "retested")}
         d["level_rays"] = list(self.level_rays[: self.levels])
         d["level_hits"] = list(self.level_hits[: self.levels])
         return d

@@ -220,6 +220,8 @@ struct WorkBufs {
   Counters* counters = nullptr;
   size_t cap_queue = 0;
   bool sort = false;                  // regroup the hits of level >= 1 by grid cell (large scenes)
+  FixRec* fix = nullptr;              // fp32 mode: (hit, light) pairs queued for the fp64 re-test (k_fix_exact)
+  size_t cap_fix = 0;
 };
 
 struct rt_scene {
@@ -236,6 +238,8 @@ struct rt_scene {
   size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
   size_t min_queue = 0;          // queue capacity requested after an overflow (rays per level)
   size_t overflow_need = 0;      // largest level size seen by the last overflowed frame
+  FixRec* d_fix = nullptr; size_t cap_fix = 0, min_fix = 0;   // re-test queue of the fp32 mode
+  int sticky_overflow = 0;       // an RT_FLAG_ASYNC frame overflowed since the last rt_sync / blocking rt_render
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
   void* d_out = nullptr;         // conversion / staging target
   HitRec* d_hits = nullptr;
@@ -262,6 +266,8 @@ static void free_workspace(rt_scene* s) {
   if (s->d_hits_sorted) hipFree(s->d_hits_sorted);
   if (s->d_sort_keys) hipFree(s->d_sort_keys);
   if (s->d_sort_table) hipFree(s->d_sort_table);
+  if (s->d_fix) hipFree(s->d_fix);
+  s->d_fix = nullptr; s->cap_fix = 0;
   s->d_hits_sorted = nullptr; s->d_sort_keys = nullptr; s->d_sort_table = nullptr;
   for (int i = 0; i < 2; ++i) { if (s->d_qbuf[i]) hipFree(s->d_qbuf[i]); if (s->d_qpix[i]) hipFree(s->d_qpix[i]); }
   s->d_fb = s->d_out = nullptr; s->d_hits = nullptr;
@@ -481,6 +487,7 @@ static void fill_stats(PendingFrame& pf, const Counters& c, rt_stats* out) {
     if (c.n_rays[l]) st.batches++;
   }
   st.shadow_rays = st.hits * (int64_t)pf.n_lights * pf.n_cells;
+  if (pf.precision == RT_FP32) for (int q = 0; q < FIX_QUEUES; ++q) st.retested += c.fixq[q * 32];
   st.segments = pf.precision == RT_FP64 ? (pf.stream ? pf.s_queries : (int64_t)c.queries) - st.shadow_rays : -1;
   if (pf.timing && !pf.events.empty()) {
     for (EventPair& ep : pf.events) {
@@ -507,13 +514,26 @@ static int drain(rt_scene* s) {
       size_t need = 0;
       for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
       s->overflow_need = need;
+      // the next frame (blocking retry, or the next async frame) gets larger queues; levels below the truncated
+      // one were undercounted, so grow generously
+      s->min_queue = std::max(s->min_queue, std::max(need + need / 4, 2 * s->cap_queue));
       rc = fail(RT_ERR_QUEUE_OVERFLOW, "bounce queue overflow (a level holds >= %zu rays, capacity %zu): a blocking "
                 "rt_render call grows the queues and retries by itself", need, s->cap_queue);
+    }
+    if (c.overflow_fix) {
+      size_t worst = 0;
+      for (int q = 0; q < FIX_QUEUES; ++q) worst = std::max<size_t>(worst, c.fixq[q * 32]);
+      s->min_fix = std::max(s->min_fix, (worst + worst / 4 + 1024) * FIX_QUEUES);
+      rc = fail(RT_ERR_QUEUE_OVERFLOW, "re-test queue overflow (a sub-queue holds %zu (hit, light) pairs, capacity %zu): a blocking "
+                "rt_render call grows the queue and retries by itself", worst, s->cap_fix / FIX_QUEUES);
     }
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))
       fprintf(stderr, "[rt debug] k_shade_ls (wave, light) pairs: %llu total, %llu without a sample loop\n",
               (unsigned long long)(c.queries >> 32), (unsigned long long)(c.queries & 0xFFFFFFFFull));
-    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & 2))
+    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 20)))
+      fprintf(stderr, "[rt debug] k_shade_ls wave cycles: hit setup %.3f, light setup + culling %.3f, sample loops (+ bounds) %.3f, chunk grab + spawn incl. barrier waits %.3f of %llu (rest: Phong, accumulate)\n",
+              (double)c.dbg[0] / (double)c.dbg[3], (double)c.dbg[1] / (double)c.dbg[3], (double)c.dbg[2] / (double)c.dbg[3], (double)c.queries / (double)c.dbg[3], (unsigned long long)c.dbg[3]);
+    else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & 2))
       fprintf(stderr, "[rt debug] shortcut audit: fully-lit claims wrong %llu, umbra claims wrong %llu, penumbra lanes %llu of %llu\n",
               (unsigned long long)c.dbg[0], (unsigned long long)c.dbg[1], (unsigned long long)c.dbg[2], (unsigned long long)c.dbg[3]);
     else if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (c.dbg[0] || c.dbg[1])) {
@@ -550,7 +570,8 @@ extern "C" int rt_sync(rt_scene* s) {
 
 static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out) {
   const size_t want_q = std::max<size_t>(2 * pixels + 1024, s->min_queue);
-  if (pixels > s->cap_pixels || want_q > s->cap_queue) {
+  const size_t want_fix = std::max<size_t>(std::max<size_t>(pixels / 8, 65536), s->min_fix);
+  if (pixels > s->cap_pixels || want_q > s->cap_queue || want_fix > s->cap_fix) {
     pixels = std::max(pixels, s->cap_pixels);
     int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
     void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
@@ -570,7 +591,9 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
       HIPCHK(hipMalloc(&s->d_qbuf[i], q * 9 * sizeof(double)));
       HIPCHK(hipMalloc(&s->d_qpix[i], q * sizeof(uint32_t)));
     }
-    s->cap_pixels = pixels; s->cap_queue = q;
+    const size_t nfix = std::max<size_t>(std::max<size_t>(pixels / 8, 65536), s->min_fix);
+    HIPCHK(hipMalloc(&s->d_fix, nfix * sizeof(FixRec)));
+    s->cap_pixels = pixels; s->cap_queue = q; s->cap_fix = nfix;
   }
   if (need_out && out_bytes > s->cap_out) {
     int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
@@ -595,6 +618,7 @@ static WorkBufs own_bufs(rt_scene* s) {
   wb.fb = s->d_fb; wb.hits = s->d_hits; wb.hits_sorted = s->d_hits_sorted; wb.sort_keys = s->d_sort_keys;
   wb.sort_table = s->d_sort_table; wb.counters = s->d_counters; wb.cap_queue = s->cap_queue; wb.sort = s->sort_hits;
   for (int i = 0; i < 2; ++i) { wb.qbuf[i] = s->d_qbuf[i]; wb.qpix[i] = s->d_qpix[i]; }
+  wb.fix = s->d_fix; wb.cap_fix = s->cap_fix;
   return wb;
 }
 
@@ -661,11 +685,18 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, sgrid, s->stream);
+        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
         if (!done)
-          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, sgrid, s->stream);
+          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
       }
     }
+  }
+  if (fr->precision == RT_FP32) {
+    // the (hit, light) pairs the fp32 kernels could not decide within their error bounds: exact fp64 shadow terms
+    Timed t(s, pf, 1);
+    const int fgrid = FIX_QUEUES * std::max(1, s->num_cu * 4 / FIX_QUEUES);
+    if (lds) hipLaunchKernelGGL(k_fix_exact<true>, dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+    else hipLaunchKernelGGL(k_fix_exact<false>, dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -844,9 +875,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   for (int attempt = 0; attempt < 6; ++attempt) {
     rc = render_locked(s, camera, fr, out, out_is_device, stats);
     if (rc != RT_ERR_QUEUE_OVERFLOW || (fr->flags & RT_FLAG_ASYNC)) break;
-    // A level outgrew the queues (more than ~2 live rays per pixel).  Levels below the truncated one
-    // were undercounted, so grow generously and render the frame again (rendering is deterministic).
-    s->min_queue = std::max(s->overflow_need + s->overflow_need / 4, 2 * s->cap_queue);
+    // A level outgrew the queues (more than ~2 live rays per pixel) or the re-test queue was too small: drain()
+    // has raised min_queue / min_fix, render the frame again (rendering is deterministic).
   }
   return rc;
 }
@@ -869,7 +899,7 @@ static int validate_frame(const rt_frame* fr, int out_is_device, int32_t* rows) 
   return rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, rows);
 }
 
-static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queue) {
+static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queue, size_t cap_fix) {
   FrameParams fp;
   fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
   fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
@@ -879,6 +909,8 @@ static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queu
   fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
   fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
   fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
+  fp.fix_cap = (uint32_t)std::min<size_t>(cap_fix / FIX_QUEUES, 0x03FFFFFFu);
+  fp.brute = (fr->flags & RT_FLAG_BRUTE_FORCE) ? 1u : 0u;
   return fp;
 }
 
@@ -907,7 +939,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (s->h_slots.empty()) { Counters* h = nullptr; HIPCHK(hipHostMalloc(&h, sizeof(Counters))); s->h_slots.push_back(h); }
   pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
 
-  const FrameParams fp = make_params(fr, rows, s->cap_queue);
+  const FrameParams fp = make_params(fr, rows, s->cap_queue, s->cap_fix);
   DevCamera cam = to_dev_camera(camera);
 
   void* fb = direct ? out : s->d_fb;
@@ -975,13 +1007,15 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   HIPCHK(hipSetDevice(s->device));
   std::lock_guard<std::mutex> dev_lk(g_static_call_mu[s->device]);
 
-  // carve-up: counters | framebuffer | hit queue | ray queue 0 | ray queue 1 | pixel indices 0 | 1
+  // carve-up: counters | framebuffer | re-test queue | hit queue | ray queue 0 | ray queue 1 | pixel indices 0 | 1
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   unsigned char* base = s->static_scratch;
   size_t off = 0;
   WorkBufs wb;
   wb.counters = (Counters*)(base + off); off += up256(sizeof(Counters));
   wb.fb = base + off; off += up256(pixels * 3 * sizeof(double));
+  wb.cap_fix = (STATIC_BYTES / 16 / sizeof(FixRec)) / FIX_QUEUES * FIX_QUEUES;   // 2 MiB of re-test records (fp32 mode)
+  wb.fix = (FixRec*)(base + off); off += up256(wb.cap_fix * sizeof(FixRec));
   const size_t per_slot = sizeof(HitRec) + 2 * (9 * sizeof(double) + sizeof(uint32_t));
   const size_t cap = ((STATIC_BYTES - off) / per_slot) & ~(size_t)63;
   wb.hits = (HitRec*)(base + off); off += cap * sizeof(HitRec);
@@ -994,7 +1028,7 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   pf.user = stats; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
   pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
   pf.precision = fr->precision; pf.timing = false;
-  const FrameParams fp = make_params(fr, rows, cap);
+  const FrameParams fp = make_params(fr, rows, cap, wb.cap_fix);
   const DevCamera cam = to_dev_camera(camera);
   const bool fb_is_double = fr->precision == RT_FP64;
   const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
@@ -1006,6 +1040,9 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   HIPCHK(hipMemcpyAsync(s->h_static, wb.counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   const Counters& c = *s->h_static;
+  if (c.overflow_fix)
+    return fail(RT_ERR_QUEUE_OVERFLOW, "rt_render_static: more (hit, light) pairs need the fp64 re-test than the static queue holds (%zu) "
+                "(this entry point cannot grow it: use rt_render, or render fewer rows per call)", wb.cap_fix);
   if (c.overflow) {
     size_t need = 0;
     for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));

@@ -43,10 +43,15 @@ struct Counters {
   uint32_t work_trace[MAX_LEVELS + 1];
   uint32_t work_shade[MAX_LEVELS + 1];
   unsigned long long queries;   // shadow-walk nearest-hit queries (fp64 kernels)
-  uint32_t overflow;
-  uint32_t pad;
+  uint32_t overflow;            // a ray / hit queue overflowed
+  uint32_t overflow_fix;        // a re-test queue overflowed (its counter keeps counting: the size it needs)
   unsigned long long dbg[4];    // RT_DEBUG_STATS=1: kernel-specific event counts
+  // fp32 mode: (hit, light) pairs queued for the exact re-test (FixRec).  FIX_QUEUES sub-queues, chosen by block
+  // index, each with its counter in a cache line of its own: a single device counter sustains only ~88 atomics
+  // per microsecond, and a 4K pool frame queues ~1e5 pairs from as many different waves.
+  uint32_t fixq[64 * 32];       // count of sub-queue q at fixq[q * 32]
 };
+constexpr int FIX_QUEUES = 64;
 
 // Radiance-ray queue of one level, struct-of-arrays so that a wave's loads/stores coalesce.
 struct RayQueue {
@@ -60,6 +65,19 @@ struct __attribute__((aligned(16))) HitRec {
   double t;
 };
 
+// fp32 mode: one (hit, light) pair whose shadow term the fp32 kernel could not decide within its error bounds
+// (a sample grazes a silhouette, touches the light, starts on a second surface, ...).  The fp32 kernel
+// contributes T = 0 for the pair and queues this record; k_fix_exact evaluates T with the literal fp64 walk
+// of the fp64 mode and adds m * T to the pixel, so every hit / miss decision of the fp32 image is the fp64 one.
+struct __attribute__((aligned(8))) FixRec {
+  double px, py, pz;     // shadow origin p = hit point + n * 1e-6 (ray_tracer.py:538)
+  float m[3];            // colour per unit of T: weight * (Kd Lc n.l + Ks Lc spec pow) * (1 - transparency) * shadow_intensity
+  uint32_t lp;           // framebuffer index of the pixel (row-set local)
+  uint32_t gpix;         // global pixel index (jitter key)
+  uint16_t level, light;
+};
+static_assert(sizeof(FixRec) == 48, "FixRec must be 48 bytes");
+
 struct FrameParams {
   RowSet rs;
   int32_t n_shadow, max_depth;
@@ -68,6 +86,8 @@ struct FrameParams {
   uint32_t debug;        // RT_DEBUG_STATS=1: kernels count events into Counters::queries (fp32 mode)
   uint32_t sequential;   // RT_FLAG_SEQUENTIAL: semantics of the reference's per-pixel render()
   double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
+  uint32_t fix_cap;      // capacity of ONE re-test sub-queue (FixRec); sub-queue q starts at fix[q * fix_cap]
+  uint32_t brute;        // RT_FLAG_BRUTE_FORCE: fp32 kernels test every surface for every shadow sample (no culling, no shortcuts)
 };
 
 __device__ __forceinline__ uint32_t global_pixel(const RowSet& rs, uint32_t lp) {
@@ -307,6 +327,67 @@ struct JitTable {               // mode A: table[((light*cells + cell)*2 + axis)
   }
 };
 
+// compute_soft_shadow_batch (ray_tracer.py:171-244) with compute_shadow_transmission_batch (:247-293) for ONE
+// (shadow origin p, light li): mean transmission over the n x n jittered samples, literal fp64.
+template <typename JIT>
+__device__ __forceinline__ double soft_shadow_exact(const DevScene& sc, const Prim* __restrict__ P, d3 p, int li, int n_sh,
+                                                    JIT& jit, int* queries, bool seq, double pthr, const Accel* ac) {
+  const double* lg = sc.lights + LIGHT_STRIDE * li;
+  const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+  double T;
+  // small scenes: conservative candidate set + fully-lit / umbra shortcut (rt_device.hpp, fan_cull)
+  PrimMask cmask = PrimMask::all();
+  bool shortcut = false;
+  if (sc.n <= 128 && (ac == nullptr || ac->n_nodes == 0)) {
+    const FanCull fc = fan_cull(sc, P, p, Lp, n_sh > 1 ? 0.7072f * (float)lg[8] : 0.0f);
+    cmask = fc.act;
+    if (!__any(fc.lane_can & !fc.lane_full)) {
+      shortcut = true;
+      T = fc.lane_full ? 0.0 : 1.0;                                              // n^2 terms of exactly 0 or 1
+      *queries += n_sh > 1 ? n_sh * n_sh : 1;                                    // one query per walk
+    }
+  }
+  if (shortcut) {
+  } else if (n_sh <= 1) {                                                               // :184-196
+    d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
+    double dist = norm3(tl);
+    d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
+    d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+    T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
+  } else {
+    d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
+    double ldist = norm3(tl);
+    d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+    d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);                  // :202-205
+    d3 right = cross3(ld, ref);                                                  // :207-209
+    double rn = norm3(right); if (rn < EPS) rn = EPS;
+    right = mk3(right.x / rn, right.y / rn, right.z / rn);
+    d3 up = cross3(right, ld);                                                   // :211-213
+    double un = norm3(up); if (un < EPS) un = EPS;
+    up = mk3(up.x / un, up.y / un, up.z / un);
+    const double radius = lg[8];
+    const double cell = radius / n_sh;                                           // :215
+    jit.begin_light(li);
+    double total = 0.0;
+    for (int i = 0; i < n_sh; ++i)
+      for (int j = 0; j < n_sh; ++j) {                                           // :219-241
+        double ui, uj;
+        jit.get(li, i * n_sh + j, &ui, &uj);
+        double oi = -radius / 2 + cell * (i + ui);
+        double oj = -radius / 2 + cell * (j + uj);
+        d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,
+                    (Lp.z + oi * right.z) + oj * up.z);
+        d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+        double dist = norm3(ts);
+        d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
+        d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
+        total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
+      }
+    T = total / (double)(n_sh * n_sh);                                           // :243
+  }
+  return T;
+}
+
 struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading result of one hit
 
 // Literal fp64 restatement of ray_tracer.py:517-563 for one hit, with compute_soft_shadow_batch
@@ -329,57 +410,7 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
   for (int li = 0; li < sc.nL; ++li) {                                             // :526
     const double* lg = sc.lights + LIGHT_STRIDE * li;
     const d3 Lp = mk3(lg[0], lg[1], lg[2]);
-    double T;
-    // small scenes: conservative candidate set + fully-lit / umbra shortcut (rt_device.hpp, fan_cull)
-    PrimMask cmask = PrimMask::all();
-    bool shortcut = false;
-    if (sc.n <= 128 && (ac == nullptr || ac->n_nodes == 0)) {
-      const FanCull fc = fan_cull(sc, P, p, Lp, n_sh > 1 ? 0.7072f * (float)lg[8] : 0.0f);
-      cmask = fc.act;
-      if (!__any(fc.lane_can & !fc.lane_full)) {
-        shortcut = true;
-        T = fc.lane_full ? 0.0 : 1.0;                                              // n^2 terms of exactly 0 or 1
-        *queries += n_sh > 1 ? n_sh * n_sh : 1;                                    // one query per walk
-      }
-    }
-    if (shortcut) {
-    } else if (n_sh <= 1) {                                                               // :184-196
-      d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
-      double dist = norm3(tl);
-      d3 dir = mk3(tl.x / dist, tl.y / dist, tl.z / dist);
-      d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-      T = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
-    } else {
-      d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                             // :198-200
-      double ldist = norm3(tl);
-      d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
-      d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);                  // :202-205
-      d3 right = cross3(ld, ref);                                                  // :207-209
-      double rn = norm3(right); if (rn < EPS) rn = EPS;
-      right = mk3(right.x / rn, right.y / rn, right.z / rn);
-      d3 up = cross3(right, ld);                                                   // :211-213
-      double un = norm3(up); if (un < EPS) un = EPS;
-      up = mk3(up.x / un, up.y / un, up.z / un);
-      const double radius = lg[8];
-      const double cell = radius / n_sh;                                           // :215
-      jit.begin_light(li);
-      double total = 0.0;
-      for (int i = 0; i < n_sh; ++i)
-        for (int j = 0; j < n_sh; ++j) {                                           // :219-241
-          double ui, uj;
-          jit.get(li, i * n_sh + j, &ui, &uj);
-          double oi = -radius / 2 + cell * (i + ui);
-          double oj = -radius / 2 + cell * (j + uj);
-          d3 sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y,
-                      (Lp.z + oi * right.z) + oj * up.z);
-          d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
-          double dist = norm3(ts);
-          d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
-          d3 so = mk3(p.x + dir.x * EPS, p.y + dir.y * EPS, p.z + dir.z * EPS);
-          total += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, queries, seq, pthr, ac, cmask);
-        }
-      T = total / (double)(n_sh * n_sh);                                           // :243
-    }
+    const double T = soft_shadow_exact(sc, P, p, li, n_sh, jit, queries, seq, pthr, ac);
     double I = (1 - lg[7]) + lg[7] * T;                                            // :543
     if (seq && I < EPS) continue;                                                  // sequential: :347-348
     d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
@@ -448,6 +479,56 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
       atomicAdd(&C->queries, (unsigned long long)queries);
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C);
+  }
+}
+
+// --------------------------------------------------------------------------- k_fix_exact -------
+// fp32 mode, after the last level: the queued (hit, light) pairs get their shadow term from the literal fp64
+// code of the fp64 mode (soft_shadow_exact: same jitter, same walk), one lane per record.  The fp32 shade
+// kernels queue a pair whenever one of its hit / miss decisions lies within the error bound of their fp32
+// arithmetic (rt_shade_ls.hpp, rt_shade_fast.hpp), and shaded it with T = 0; the colour is linear in T.
+template <bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp, const FixRec* __restrict__ fix,
+                                                     Counters* C, float* __restrict__ fb) {
+  __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
+  __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
+  // block -> (sub-queue, slice): grid = FIX_QUEUES * slices
+  const uint32_t qi = blockIdx.x % FIX_QUEUES, slice = blockIdx.x / FIX_QUEUES, n_slices = gridDim.x / FIX_QUEUES;
+  uint32_t count = C->fixq[qi * 32];
+  if (count > fp.fix_cap) count = fp.fix_cap;
+  if (slice * BLOCK >= count) return;           // (uniform over the block; most blocks of most frames)
+  const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
+  const FixRec* __restrict__ mine = fix + (size_t)qi * fp.fix_cap;
+  for (uint32_t base = slice * BLOCK; base < count; base += n_slices * BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    {
+      // the idle lanes of a sub-queue's last wave re-test a copy of its last record (result dropped): the
+      // conservative pre-pass of soft_shadow_exact (fan_cull) is wave-level
+      const bool live = i < count;
+      const FixRec rec = mine[live ? i : count - 1];
+      JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = rec.gpix; jit.depth = rec.level;
+      int queries = 0;
+      const double T = soft_shadow_exact(sc, P, mk3(rec.px, rec.py, rec.pz), (int)rec.light, fp.n_shadow, jit, &queries,
+                                         false, fp.plane_thr, &ac);
+      float* dst = fb + 3 * (size_t)rec.lp;
+      const float Tf = (float)T;
+      if (live && Tf != 0.0f) { atomicAdd(dst + 0, rec.m[0] * Tf); atomicAdd(dst + 1, rec.m[1] * Tf); atomicAdd(dst + 2, rec.m[2] * Tf); }
+    }
+  }
+}
+
+// Queue one (hit, light) pair for the exact re-test.  Must be called convergently by every lane of the wave.
+__device__ __forceinline__ void queue_fix(bool pred, FixRec* __restrict__ fix, Counters* C, const FrameParams& fp, d3 p,
+                                          float m0, float m1, float m2, uint32_t lp, uint32_t gpix, int level, int li) {
+  const uint32_t qi = blockIdx.x % FIX_QUEUES;
+  const uint32_t slot = wave_append(&C->fixq[qi * 32], pred);
+  if (pred) {
+    if (slot < fp.fix_cap) {
+      FixRec r; r.px = p.x; r.py = p.y; r.pz = p.z; r.m[0] = m0; r.m[1] = m1; r.m[2] = m2;
+      r.lp = lp; r.gpix = gpix; r.level = (uint16_t)level; r.light = (uint16_t)li;
+      fix[(size_t)qi * fp.fix_cap + slot] = r;
+    } else C->overflow_fix = 1u;   // (the frame is rendered again with a larger queue, like a ray-queue overflow)
   }
 }
 

@@ -51,7 +51,7 @@ constexpr int WAVE_REC_CAP = 128;     // records a (wave, light) list holds; mor
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCENE && CH <= 9) ? 2 : 1))) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
-                                                      float* __restrict__ fb, int n_chunks) {
+                                                      float* __restrict__ fb, int n_chunks, FixRec* __restrict__ fix) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
   __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];
   __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
       // Large scene: ball (cw, rho) around the wave's hits.  A wave's hits are compact (8x8 pixel tile, or
       // neighbours in the queue), so the hierarchy is first scanned ONCE per (wave, light) with the hull
       // of all its shadow fans (bvh_wave_leaves); the lanes then test only the leaves that survive.
-      const bool coop = !LDS_SCENE && ac.n_nodes > 0 && !(RT_DBG(fp) & 64u);
+      const bool coop = !LDS_SCENE && ac.n_nodes > 0 && !(RT_DBG(fp) & 64u) && !fp.brute;
       f3 cw = mkf(0, 0, 0); float rho = 0.0f;
       if (coop) {
         const f3 pf = tof(p);
@@ -127,6 +127,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         const float half = -0.5f * radius;
         const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
         float total = 0.0f;
+        // Exactness of the fp32 decisions (see rt_shade_ls.hpp): unc >= 0 after the sample blocks means that some
+        // hit / miss decision of this (hit, light) lay within the error bound of its fp32 arithmetic; the pair is
+        // then shaded with T = 0 and queued for the fp64 re-test (k_fix_exact).  Bounds: the unit directions carry
+        // <= 8 ulp (absolute), oc / cc / num / slab offsets are rounded from fp64 (1 ulp, relative).
+        float unc = -1.0f;
+        constexpr float U8 = 12.0f * 6.0e-8f;
+        const float RLx = n_sh > 1 ? 0.7072f * radius * 1.001f : 0.0f;
+        const float T0x = dotf(tl, tl);
+        // the light within 3 sample-square radii of the hit, or the 0.9 switch of the basis within rounding
+        if ((T0x < 9.0f * RLx * RLx) | (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f) | !(T0x > 1e-12f)) unc = 1.0f;
+        // reach of the sample square + the error of a shadow segment's far end (grows with the segment's length)
+        const float reach = RLx + 1e-5f * (1.0f + fabsf((float)lg[0]) + fabsf((float)lg[1]) + fabsf((float)lg[2])) + 2.0f * U8 * raw_sqrt(T0x);
         // LDS-staged scenes (<= 128 records): conservative candidate set of this (wave, light) and the
         // fully-lit / umbra shortcut (rt_device.hpp, fan_cull) — the sample blocks below run only for
         // records whose bound can touch some lane's shadow fan.
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           const FanCull fc = fan_cull(sc, P, p, mk3(lg[0], lg[1], lg[2]), n_sh > 1 ? 0.7072f * radius : 0.0f);
           cand = fc.act; lane_lit = !fc.lane_can; lane_dark = fc.lane_full;
           skip_samples = !(RT_DBG(fp) & 2u) && !__any(fc.lane_can & !fc.lane_full);
+          if (fp.brute) { cand.lo = cand.hi = ~0ull; lane_lit = lane_dark = false; skip_samples = false; }   // RT_FLAG_BRUTE_FORCE
         }
         if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
         int n_wl = -1, n_wr = -1;
@@ -233,10 +246,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float cc = (float)(((ocx * ocx + ocy * ocy) + ocz * ocz) - s_.a[4]);
             const f3 oc = mkf((float)ocx, (float)ocy, (float)ocz);
             const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+            // error bounds of this (hit, sphere): |disc error| <= kap |b| + kap0 with e_b = 8 ulp * |oc|
+            const float r_ = (float)s_.a[3];
+            const float ocn = raw_sqrt(fmaxf(cc + r_ * r_, 0.0f));
+            const float e_b = U8 * ocn, kap = 4.0f * e_b, kap0 = 4.0f * e_b * e_b + 4.0f * 6.0e-8f * fabsf(cc);
+            {   // a sample of the light may lie on the sphere (crossing at the far end of the segment)
+              const float lx = (float)(lg[0] - s_.a[0]), ly = (float)(lg[1] - s_.a[1]), lz = (float)(lg[2] - s_.a[2]);
+              const float dl = raw_sqrt(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
+              if (fabsf(dl - r_) <= reach + 1e-5f * (dl + r_)) unc = 1.0f;
+            }
+            // a root can only come near the 2e-6 bound when p lies within ~1e-5 of the sphere's surface
+            // (t1 t2 = cc): the hit's own sphere, or one touching it at the hit point
+            const bool nearsurf = fabsf(cc) <= 1.2e-5f * (ocn + r_);
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float b = fmaf(oc.z, dz[s], fmaf(oc.y, dy[s], oc.x * dx[s]));   // oc.d  (a = d.d = 1)
-              const float sq = raw_sqrt(fmaf(b, b, -cc));               // NaN on a miss: both tests fail
+              const float disc = fmaf(b, b, -cc);
+              unc = fmaxf(unc, fmaf(kap, fabsf(b), kap0) - fabsf(disc));   // the ray grazes the silhouette within rounding
+              const float sq = raw_sqrt(disc);                          // NaN on a miss: both tests fail
               // roots {q, cc/q} with q the root that does not cancel: the other one can be the crossing of
               // the hit's own sphere at t' ~ 1e-6/cos, which has to be compared with the 2e-6 bound
               const float t1 = b < 0.0f ? sq - b : -b - sq;
@@ -245,12 +272,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const bool in2 = (t2 > T_LO) & (t2 < md[s]);
               if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
               else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+              if (nearsurf) {
+                // a root within 1e-3 (relative) of the 2e-6 bound is not decided in fp32 — unless the other root blocks
+                // an opaque scene's sample anyway
+                const bool n1 = fabsf(t1 - T_LO) <= 1e-3f * T_LO, n2 = fabsf(t2 - T_LO) <= 1e-3f * T_LO;
+                const bool open_ = OPAQUE ? !((in1 & !n1) | (in2 & !n2)) : true;
+                if ((n1 | n2) & open_) unc = 1.0f;
+              }
             }
           };
           auto do_box = [&](const Prim& s_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
             const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
             const f3 hi = mkf((float)(s_.a[3] - p.x), (float)(s_.a[4] - p.y), (float)(s_.a[5] - p.z));
             const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+            {   // a sample of the light may lie on the box's surface: inside the box grown by `reach`, not inside it shrunk
+              const float g_ = reach + 1e-5f * (fabsf(lo.x) + fabsf(lo.y) + fabsf(lo.z) + fabsf(hi.x) + fabsf(hi.y) + fabsf(hi.z));
+              const bool big = (tl.x >= lo.x - g_) & (tl.x <= hi.x + g_) & (tl.y >= lo.y - g_) & (tl.y <= hi.y + g_) & (tl.z >= lo.z - g_) & (tl.z <= hi.z + g_);
+              const bool small_ = (tl.x > lo.x + g_) & (tl.x < hi.x - g_) & (tl.y > lo.y + g_) & (tl.y < hi.y - g_) & (tl.z > lo.z + g_) & (tl.z < hi.z - g_);
+              if (big & !small_) unc = 1.0f;
+            }
+            // p within ~1e-5 of one of the box's face planes: slab roots can come near the 2e-6 bound
+            const float fmin_ = fminf(fminf(fminf(fabsf(lo.x), fabsf(hi.x)), fminf(fabsf(lo.y), fabsf(hi.y))), fminf(fabsf(lo.z), fabsf(hi.z)));
+            const bool nearsurf = fmin_ <= 1.2e-5f;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float jx = KEEP_INV ? ix[KEEP_INV ? s : 0] : raw_rcp(dx[s]), jy = KEEP_INV ? iy[KEEP_INV ? s : 0] : raw_rcp(dy[s]),
@@ -265,6 +308,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const bool in2 = ok & (tf > T_LO) & (tf < md[s]);
               if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
               else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
+              // the ray passes an edge of the box within the slabs' rounding: each slab value carries the relative error
+              // of 1/d (8 ulp of a unit vector's component) plus a few ulp; a component within 1e-3 of parallel is never decided
+              const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
+              const float rel = fmaf(U8, jm, 4.0f * 6.0e-8f);
+              if ((fabsf(tf - tn) <= 2.0f * rel * (fabsf(tn) + fabsf(tf))) | (jm > 1e3f)) unc = 1.0f;
+              if (nearsurf) {
+                const bool n1 = fabsf(tn - T_LO) <= 1e-3f * T_LO, n2 = fabsf(tf - T_LO) <= 1e-3f * T_LO;
+                const bool open_ = OPAQUE ? !((in1 & !n1) | (in2 & !n2)) : true;
+                if (ok & (n1 | n2) & open_) unc = 1.0f;
+              }
             }
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
@@ -273,6 +326,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
             const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
             const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+            // a sample of the light may lie on the plane (crossing at the far end of the segment)
+            if (fabsf(fmaf(N.z, tl.z, fmaf(N.y, tl.y, N.x * tl.x)) - num) <= reach + 1e-5f * fabsf(num)) unc = 1.0f;
+            const bool nearsurf = fabsf(num) <= 1.2e-5f;                 // p on the plane: the hit's own plane
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float den = fmaf(N.z, dz[s], fmaf(N.y, dy[s], N.x * dx[s]));
@@ -280,9 +336,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const bool in1 = (t1 > T_LO) & (t1 < md[s]);               // den == 0 -> inf/NaN -> no hit
               if (OPAQUE) { tr[s] = in1 ? 0.0f : tr[s]; }
               else tr[s] *= in1 ? tau : 1.0f;
+              unc = fmaxf(unc, 2.0f * U8 - fabsf(den));                   // ray parallel to the plane within rounding
+              if (nearsurf & (fabsf(t1 - T_LO) <= 1e-3f * T_LO)) unc = 1.0f;
             }
           }
-          if (!LDS_SCENE && ac.n_nodes > 0) {
+          if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {
             // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
             // to this light (all samples lie within RL of the light centre) and runs the sample block
             // only for the spheres / boxes that can cross one of them.  Results are those of the
@@ -496,6 +554,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           if (!lane_lit && !lane_dark) atomicAdd(&C->dbg[2], 1ull);
           atomicAdd(&C->dbg[3], 1ull);
         }
+        bool undecided = !skip_samples & (unc >= 0.0f);
+        // the conservative claims of fan_cull are exact whatever the sample blocks computed for the lane
+        if (LDS_SCENE && lane_lit) { total = (float)n_cells; undecided = false; }
+        if (LDS_SCENE && OPAQUE && lane_dark) { total = 0.0f; undecided = false; }
+        undecided &= active;
+        if (undecided) total = 0.0f;
         const float T = total * inv_cells;
         const float I = fmaf((float)lg[7], T, 1.0f - (float)lg[7]);                       // ray_tracer.py:543
         const f3 l = normalize_clamped(mkf((float)(lg[0] - hp.x), (float)(lg[1] - hp.y), (float)(lg[2] - hp.z)));
@@ -513,6 +577,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         spc[0] = fmaf((float)mat[3] * (float)lg[3], s2, spc[0]);
         spc[1] = fmaf((float)mat[4] * (float)lg[4], s2, spc[1]);
         spc[2] = fmaf((float)mat[5] * (float)lg[5], s2, spc[2]);
+        if (__any(undecided)) {
+          // colour per unit of T of this (hit, light), times weight and (1 - transparency)
+          const float cm = (float)lg[7] * (1.0f - (float)mat[10]), sp = pw * (float)lg[6];
+          queue_fix(undecided, fix, C, fp, p, (float)r.w.x * cm * (float)lg[3] * fmaf((float)mat[0], ndl, (float)mat[3] * sp),
+                    (float)r.w.y * cm * (float)lg[4] * fmaf((float)mat[1], ndl, (float)mat[4] * sp),
+                    (float)r.w.z * cm * (float)lg[5] * fmaf((float)mat[2], ndl, (float)mat[5] * sp), r.lp, gpix, level, li);
+        }
       }
       const float one_m = 1.0f - (float)mat[10];
       float bt[3] = {0.0f, 0.0f, 0.0f};
@@ -542,12 +613,12 @@ static inline int pick_chunk(int n_cells) {
 
 template <int CH>
 static void launch_shade_fast_ch(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
-                                 RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                                 RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
                                  hipStream_t st, int n_chunks) {
   const bool lds = ds.n <= LDS_PRIMS, box = ds.nB > 0;
 #define RT_LAUNCH(OP, BX, LD)                                                                                     \
   hipLaunchKernelGGL((k_shade_fast<CH, OP, BX, LD>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, \
-                     hits, C, fb, n_chunks)
+                     hits, C, fb, n_chunks, fix)
   if (opaque) {
     if (!box && lds) RT_LAUNCH(true, false, true);
     else if (lds) RT_LAUNCH(true, true, true);
@@ -561,17 +632,17 @@ static void launch_shade_fast_ch(const DevScene& ds, bool opaque, const DevCamer
 }
 
 static void launch_shade_fast(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
-                              RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                              RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
                               hipStream_t st) {
   const int n_cells = fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1;
   const int ch = pick_chunk(n_cells);
   const int n_chunks = (n_cells + ch - 1) / ch;
   switch (ch) {
-    case 25: launch_shade_fast_ch<25>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
-    case 16: launch_shade_fast_ch<16>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
-    case 9: launch_shade_fast_ch<9>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
-    case 4: launch_shade_fast_ch<4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
-    default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, grid, st, n_chunks); break;
+    case 25: launch_shade_fast_ch<25>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
+    case 16: launch_shade_fast_ch<16>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
+    case 9: launch_shade_fast_ch<9>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
+    case 4: launch_shade_fast_ch<4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
+    default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
   }
 }
 

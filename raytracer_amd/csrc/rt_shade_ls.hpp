@@ -1,9 +1,9 @@
 // rt_shade_ls.hpp — fp32 shading kernel for small scenes in "light space": the dominant kernel of
 // the headline benchmark (pool.txt class: <= MAXS spheres, MAXP planes, MAXB boxes).
 //
-// Same contract as k_shade_small / k_shade_fast (see rt_shade_fast.hpp for why the product over
-// all surface crossings equals the reference's shadow walk, ray_tracer.py:247-293, and why the
-// origin-dependent terms are formed in fp64 from the exact hit point).  What is new here:
+// Same contract as k_shade_fast (see rt_shade_fast.hpp for why the product over all surface
+// crossings equals the reference's shadow walk, ray_tracer.py:247-293, and why the origin-dependent
+// terms are formed in fp64 from the exact hit point).  What is particular here:
 //
 //  * A shadow sample of light L is S = Lp + oi*right + oj*up (ray_tracer.py:224-229), so the
 //    UNNORMALISED shadow vector is ts = tl + oi*right + oj*up with tl = Lp - p.  Every dot product
@@ -14,11 +14,13 @@
 //    and the ray p + tau*ts reaches the sample at tau = 1.  A sphere crossing solves
 //        tau*|ts|^2 = -(oc.ts) +- sqrt((oc.ts)^2 - |ts|^2*cc),   in range iff 0 < tau*|ts|^2 < |ts|^2.
 //    No per-sample normalisation (no rsq, no direction vector), 2 FMAs instead of a 3-term dot per
-//    sphere, and only (oi, oj, |ts|^2) per sample: the loop nest can be sample-outer /
-//    primitive-inner with all primitive terms in registers and no per-sample arrays.
+//    sphere, and only (oi, oj, |ts|^2) per sample: the loop nest is sample-outer / primitive-inner
+//    with all primitive terms in registers and no per-sample arrays.
 //  * Two samples are processed per iteration in the two halves of 64-bit register pairs
-//    (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): measured on MI355X, packed FMA issues ~1.25x
-//    the flops of v_fma_f32 (profiles/r01_valu_rates_microbench.txt).
+//    (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The per-primitive coefficients are kept as PAIRS OF
+//    DIFFERENT scalars — (A, B), (C, cc), (D0, D1), (D2, num), two spheres' root signs — and broadcast
+//    into both halves by the instruction's op_sel bits, so a coefficient costs one register, not a
+//    splatted pair (lo2 / hi2 below; see ls_light_sum for how the broadcast is kept inside the loop).
 //  * The in-range test "0 < u < d2" is ONE unsigned integer compare on the float bit patterns
 //    (negative u and NaN from a negative discriminant both have larger bit patterns than any
 //    positive finite d2).  The lower bound is 0 instead of the reference's 2e-6 along the ray; the
@@ -28,6 +30,15 @@
 //    by a per-wave slow path (LO) taken only when some lane has that configuration; the same path
 //    applies the bound to the hit's own sphere / box when the outcome can depend on it (light inside
 //    the own primitive, or transparency anywhere in the scene).
+//  * EVERY hit / miss decision is the fp64 mode's decision.  The loop tracks, per (hit, light), how close
+//    any of its decisions came to its threshold relative to a bound on the fp32 error of the quantity
+//    compared (LsTol): discriminants near zero (a sample grazing a silhouette), roots near 0 (a second
+//    surface at the shadow origin), denominators near zero, the 2e-6 bound of the LO path, the 0.9 switch
+//    of the light basis; crossings near the sample itself are excluded per (light, primitive) on the host
+//    side of the block (s_lstr: the light's square touches the primitive).  A pair with such a decision is
+//    shaded with T = 0 and queued (FixRec); k_fix_exact adds its exact fp64 shadow term afterwards.
+//    north_star: "fp32 fast mode within <= 1/255 per 8-bit channel" — met on every channel, because no
+//    shadow sample can flip (tests/test_gpu_parity.py gates on the maximum, not on a fraction).
 #pragma once
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
@@ -37,27 +48,50 @@ namespace rt {
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f lo2(v2f a) { return __builtin_shufflevector(a, a, 0, 0); }   // -> op_sel broadcast
+__device__ __forceinline__ v2f hi2(v2f a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ v2f mk2(float x, float y) { v2f r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ v2f pk_sqrt(v2f a) { v2f r; r.x = raw_sqrt(a.x); r.y = raw_sqrt(a.y); return r; }
 __device__ __forceinline__ v2f pk_rcp(v2f a) { v2f r; r.x = raw_rcp(a.x); r.y = raw_rcp(a.y); return r; }
 // 0 <= u < hi for hi positive finite, as ONE unsigned compare of the bit patterns: negative u
 // (sign bit set), NaN and +inf all compare above any positive finite hi.
 __device__ __forceinline__ bool in_open(float u, float hi) { return __float_as_uint(u) < __float_as_uint(hi); }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
 
 constexpr int LS_MAX_CELLS = 1024;   // lights x n^2 entries of the per-block sample table (8 KiB)
 constexpr int LS_MAX_LIGHTS = 16;    // lights / materials staged in LDS (uniform global loads inside the
 constexpr int LS_MAX_MATS = 32;      // light loop were emitted as vector loads + full-latency waits)
+constexpr float LS_U = 6.0e-8f;      // 2^-24, the unit roundoff of fp32
 
 // Per-hit (cc, sgn, num, box slabs) and per-light (A, B, C, D*) primitive terms live in plain local
 // arrays of the kernel (fully unrolled, compile-time indices -> VGPRs); this is a view of references
 // so the sample loop can be a function.  (A struct of arrays was partly promoted to LDS by hipcc.)
 template <int MAXS, int MAXP, int MAXB, bool OPAQUE>
 struct LsPrims {
-  const float (&cc)[MAXS]; const float (&A)[MAXS]; const float (&B)[MAXS]; const float (&C)[MAXS];
-  const float (&sgn)[MAXS]; const float (&tauS)[MAXS];
-  const float (&num)[MAXP]; const float (&D0)[MAXP]; const float (&D1)[MAXP]; const float (&D2)[MAXP]; const float (&tauP)[MAXP];
+  // (the coefficient pairs are non-const: ls_light_sum passes them through empty asm statements, values unchanged)
+  v2f (&AB)[MAXS];                             // (A, B) = (oc.tl, oc.right)
+  v2f (&Cc)[MAXS];                             // (C, cc) = (oc.up, |oc|^2 - r^2)
+  v2f (&Sg)[(MAXS + 1) / 2];                   // root signs of spheres (2j, 2j+1): +1 far root (origin inside), -1 near root
+  const float (&tauS)[MAXS];
+  v2f (&D01)[MAXP]; v2f (&D2n)[MAXP];          // (N.tl, N.right), (N.up, offset - p.N)
+  const float (&tauP)[MAXP];
   const float (&blo)[MAXB > 0 ? MAXB : 1][3]; const float (&bhi)[MAXB > 0 ? MAXB : 1][3];
   const float (&tauB)[MAXB > 0 ? MAXB : 1]; const bool (&binside)[MAXB > 0 ? MAXB : 1];
 };
+
+// Error bounds of one (hit, light), all derived from the magnitudes that enter its fp32 arithmetic.
+struct LsTol {
+  float kap;      // |disc error| <= kap*|oc.ts| + kap0 around a vanishing discriminant
+  float kap0;
+  float elo;      // roots u (= distance along the ray times |ts|) up to elo count as "at the shadow origin"
+  float eden;     // |N.ts| up to eden counts as "parallel to the plane"
+};
+struct LsFlags { float unc; uint32_t mlow; float dmin; };   // what the loop tracks (see ls_decided)
+__device__ __forceinline__ LsFlags ls_flags_init() { LsFlags f; f.unc = -3.0e38f; f.mlow = 0xFFFFFFFFu; f.dmin = 3.0e38f; return f; }
+// true: every decision of the pair kept clear of its threshold by more than the fp32 error bound
+__device__ __forceinline__ bool ls_decided(const LsFlags& f, const LsTol& t) {
+  return (f.unc < -t.kap0) & (f.mlow > __float_as_uint(t.elo)) & (f.dmin > t.eden);
+}
 
 // Transmission sum of one light for one hit: sum over the n x n cells of the product of blocker
 // transparencies (opaque scenes: count of unblocked cells).  Two cells per iteration.
@@ -66,22 +100,33 @@ struct LsPrims {
 // expressed as u = tau*|ts|^2 and folded into an UNSIGNED MINIMUM of float bit patterns
 // (v_min_u32 / v_min3_u32); the cell is blocked iff min_bits < bits(|ts|^2) (see in_open).  A
 // compare per test would put ~3 SALU mask operations per VALU compare into the wave's instruction
-// stream (measured: 170 SALU vs 134 VALU instructions per pair, no faster than k_shade_small).
+// stream (measured: 170 SALU vs 134 VALU instructions per pair).
 // NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6; unused slots hold A = B = C = 0,
-// cc = 1 (negative discriminant, never hit), so the sphere loop has no guards or branches.
+// cc = 1 (negative discriminant, never hit), so the sphere loop has no guards.
 template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool LO>
-__device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
+__device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
                                               const float2* __restrict__ cells, int n_cells, JitKey key, float cell32,
-                                              f3 tl, f3 right, f3 up, float T0, float T1, float T2, int own = -1) {
+                                              f3 tl, f3 right, f3 up, float T0, float T1, float T2, float kap,
+                                              LsFlags& fl, int own = -1) {
   float total = 0.0f;
   const int n_pairs = (n_cells + 1) >> 1;
+  // The coefficient pairs pass through an empty asm statement in every iteration (values unchanged): that makes
+  // them loop-variant for the optimiser, so the broadcasts lo2() / hi2() stay inside the loop body, where
+  // instruction selection folds them into the op_sel bits of the packed instruction.  (Loop-invariant, they are
+  // hoisted as splatted register pairs: twice the registers — the kernel then sits at the 256-VGPR limit of
+  // 2 waves/SIMD.)  The asm works on the kernel's own arrays, not on copies: a copy would double the registers
+  // of the values that stay live for the next light (cc, num, the root signs).
+  v2f (&AB)[MAXS] = pr.AB; v2f (&Cc)[MAXS] = pr.Cc; v2f (&Sg)[(MAXS + 1) / 2] = pr.Sg;
+  v2f (&D01)[MAXP] = pr.D01; v2f (&D2n)[MAXP] = pr.D2n;
+  float unc = fl.unc, dmin = fl.dmin;
+  uint32_t mlow = fl.mlow;
   // LO: coefficients of the lane's OWN sphere (selected once; the slow path is rare and must not
   // raise the kernel's register budget, so only the own sphere gets the two-root treatment)
   float oA = 0.0f, oB = 0.0f, oC = 0.0f, occ = 1.0f, otau = 1.0f;
   if (LO) {
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (own == k) { oA = pr.A[k]; oB = pr.B[k]; oC = pr.C[k]; occ = pr.cc[k]; if (!OPAQUE) otau = pr.tauS[k]; }
+      if (own == k) { oA = AB[k].x; oB = AB[k].y; oC = Cc[k].x; occ = Cc[k].y; if (!OPAQUE) otau = pr.tauS[k]; }
   }
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
@@ -89,6 +134,12 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
   uint32_t xa = key.a + JIT_PHI_A, xb = key.b + JIT_PHI_B;                  // cell 0 (see jit_ui / jit_uj)
 #pragma unroll 1
   for (int q = 0; q < n_pairs; ++q) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { asm("" : "+v"(AB[k])); asm("" : "+v"(Cc[k])); }
+#pragma unroll
+    for (int k = 0; k < (NS + 1) / 2; ++k) asm("" : "+v"(Sg[k]));
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) { asm("" : "+v"(D01[k])); asm("" : "+v"(D2n[k])); }
     const int c0 = 2 * q, c1 = 2 * q + 1;
     const bool valid1 = c1 < n_cells;                                       // wave-uniform
     const float2 b0 = nb0, b1 = nb1;
@@ -102,15 +153,20 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
     xa += 2u * JIT_PHI_A; xb += 2u * JIT_PHI_B;                             // jitter lattice of the next pair
     const v2f d2 = pk_fma(oi, splat(T1) + oi, pk_fma(oj, splat(T2) + oj, splat(T0)));   // |ts|^2
     uint32_t m0 = 0xFFFFFFFFu, m1 = valid1 ? 0xFFFFFFFFu : 0u;             // min of candidate bit patterns
+    uint32_t ml = 0xFFFFFFFFu;                                              // transparent scenes: smallest positive root
     v2f tr = splat(1.0f);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {                                          // spheres: sphere.py:49-71
       if (!(act & (1u << k))) continue;                                     // culled for this (wave, light)
-      const v2f bt = pk_fma(oj, splat(pr.C[k]), pk_fma(oi, splat(pr.B[k]), splat(pr.A[k])));   // oc.ts
-      const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(pr.cc[k]))));                         // NaN on a miss
+      const v2f bt = pk_fma(oj, lo2(Cc[k]), pk_fma(oi, hi2(AB[k]), lo2(AB[k])));                 // oc.ts
+      const v2f disc = pk_fma(bt, bt, -(d2 * hi2(Cc[k])));
+      const v2f sq = pk_sqrt(disc);                                                              // NaN on a miss
+      const v2f sg = (k & 1) ? hi2(Sg[k >> 1]) : lo2(Sg[k >> 1]);
+      // a discriminant within its error bound of zero: the sample grazes the silhouette
+      unc = fmaxf(unc, fmaxf(fmaf(kap, fabsf(bt.x), -fabsf(disc.x)), fmaf(kap, fabsf(bt.y), -fabsf(disc.y))));
       if (LO) {                                                             // own sphere: handled after the loop
         if (OPAQUE) {
-          v2f u = pk_fma(splat(pr.sgn[k]), sq, -bt);
+          v2f u = pk_fma(sg, sq, -bt);
           if (own == k) u = splat(-1.0f);
           m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y));
         } else {
@@ -118,17 +174,20 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
           const float ta = own == k ? 1.0f : pr.tauS[k];
           tr.x *= in_open(u1.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u1.y, d2.y) ? ta : 1.0f;
           tr.x *= in_open(u2.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u2.y, d2.y) ? ta : 1.0f;
+          if (own != k) ml = min(ml, min(umin3(__float_as_uint(u1.x), __float_as_uint(u2.x), __float_as_uint(u1.y)), __float_as_uint(u2.y)));
         }
       } else if (OPAQUE) {
-        const v2f u = pk_fma(splat(pr.sgn[k]), sq, -bt);                    // far root iff origin inside
+        const v2f u = pk_fma(sg, sq, -bt);                                  // far root iff origin inside
         m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y));
       } else {
         const v2f u1 = -bt - sq, u2 = sq - bt;
         const float ta = pr.tauS[k];
         tr.x *= in_open(u1.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u1.y, d2.y) ? ta : 1.0f;
         tr.x *= in_open(u2.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u2.y, d2.y) ? ta : 1.0f;
+        ml = min(ml, min(umin3(__float_as_uint(u1.x), __float_as_uint(u2.x), __float_as_uint(u1.y)), __float_as_uint(u2.y)));
       }
     }
+    if (LO && OPAQUE) mlow = umin3(mlow, m0, valid1 ? m1 : 0xFFFFFFFFu);   // the other spheres' roots at the shadow origin
     if (LO) {
       // The lane's own sphere with the reference's lower bound t' = u/|ts| > 2e-6 on both roots
       // (u^2 > 4e-12 |ts|^2): a shadow ray that crosses the surface it starts on does so at
@@ -136,13 +195,22 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
       // 1e-6).  The small root is formed as |ts|^2 cc / (large root) to avoid the cancellation of
       // -bt -+ sqrt(..) at that scale.  occ = 1 (no own sphere): negative discriminant, nothing happens.
       const v2f bt = pk_fma(oj, splat(oC), pk_fma(oi, splat(oB), splat(oA)));
-      const v2f sq = pk_sqrt(pk_fma(bt, bt, -(d2 * splat(occ))));
+      const v2f disc = pk_fma(bt, bt, -(d2 * splat(occ)));
+      const v2f sq = pk_sqrt(disc);
       v2f u2;
       u2.x = bt.x < 0.0f ? sq.x - bt.x : -bt.x - sq.x; u2.y = bt.y < 0.0f ? sq.y - bt.y : -bt.y - sq.y;
       const v2f u1 = d2 * splat(occ) * pk_rcp(u2);                          // u1 * u2 = |ts|^2 cc
-      const v2f lo2 = d2 * splat(T_LO * T_LO);
-      const bool a0 = in_open(u1.x, d2.x) & (u1.x * u1.x > lo2.x), a1 = in_open(u1.y, d2.y) & (u1.y * u1.y > lo2.y);
-      const bool b0 = in_open(u2.x, d2.x) & (u2.x * u2.x > lo2.x), b1 = in_open(u2.y, d2.y) & (u2.y * u2.y > lo2.y);
+      const v2f lo2_ = d2 * splat(T_LO * T_LO);
+      const v2f s1 = u1 * u1, s2 = u2 * u2;
+      const bool a0 = in_open(u1.x, d2.x) & (s1.x > lo2_.x), a1 = in_open(u1.y, d2.y) & (s1.y > lo2_.y);
+      const bool b0 = in_open(u2.x, d2.x) & (s2.x > lo2_.x), b1 = in_open(u2.y, d2.y) & (s2.y > lo2_.y);
+      if (own >= 0 && own < NS) {
+        // a root within 1e-3 (relative, squared) of the 2e-6 bound is not decided in fp32
+        const bool nr = (fabsf(s1.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s1.y - lo2_.y) <= 1e-3f * lo2_.y) |
+                        (fabsf(s2.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s2.y - lo2_.y) <= 1e-3f * lo2_.y);
+        unc = nr ? 3.0e38f : unc;
+        unc = fmaxf(unc, fmaxf(fmaf(kap, fabsf(bt.x), -fabsf(disc.x)), fmaf(kap, fabsf(bt.y), -fabsf(disc.y))));
+      }
       if (OPAQUE) {
         m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1;                 // 0 = "blocked" for the final compare
       } else {
@@ -153,22 +221,37 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
       if (act & (0x10000u << k)) {
-        const v2f den = pk_fma(oj, splat(pr.D2[k]), pk_fma(oi, splat(pr.D1[k]), splat(pr.D0[k])));   // N.ts
-        const v2f tau = splat(pr.num[k]) * pk_rcp(den);                    // den == 0 -> inf/NaN -> miss
+        const v2f den = pk_fma(oj, lo2(D2n[k]), pk_fma(oi, hi2(D01[k]), lo2(D01[k])));   // N.ts
+        const v2f tau = hi2(D2n[k]) * pk_rcp(den);                          // den == 0 -> inf/NaN -> miss
         v2f u = tau * d2;                                                   // same scale as the sphere roots
+        dmin = fminf(dmin, fminf(fabsf(den.x), fabsf(den.y)));              // ray parallel to the plane within rounding
         if (LO) {   // exact lower bound of the reference: tau*|ts| > 2e-6 (own plane, light behind it)
           const v2f t2 = tau * u;
+          const bool nr = (fabsf(t2.x - T_LO * T_LO) <= 1e-3f * T_LO * T_LO) | (fabsf(t2.y - T_LO * T_LO) <= 1e-3f * T_LO * T_LO);
+          unc = nr ? 3.0e38f : unc;
           u.x = t2.x > T_LO * T_LO ? u.x : -1.0f; u.y = t2.y > T_LO * T_LO ? u.y : -1.0f;
         }
         if (OPAQUE) { m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y)); }
-        else { const float ta = pr.tauP[k]; tr.x *= in_open(u.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u.y, d2.y) ? ta : 1.0f; }
+        else {
+          const float ta = pr.tauP[k]; tr.x *= in_open(u.x, d2.x) ? ta : 1.0f; tr.y *= in_open(u.y, d2.y) ? ta : 1.0f;
+          if (!LO) ml = umin3(ml, __float_as_uint(u.x), __float_as_uint(u.y));
+        }
       }
     }
     if (MAXB > 0) {                                                         // boxes: cube.py:76-107 (slab roots)
       if (nB > 0) {
-        const v2f ix = pk_rcp(pk_fma(oj, splat(up.x), pk_fma(oi, splat(right.x), splat(tl.x))));
-        const v2f iy = pk_rcp(pk_fma(oj, splat(up.y), pk_fma(oi, splat(right.y), splat(tl.y))));
-        const v2f iz = pk_rcp(pk_fma(oj, splat(up.z), pk_fma(oi, splat(right.z), splat(tl.z))));
+        const v2f tsx = pk_fma(oj, splat(up.x), pk_fma(oi, splat(right.x), splat(tl.x)));
+        const v2f tsy = pk_fma(oj, splat(up.y), pk_fma(oi, splat(right.y), splat(tl.y)));
+        const v2f tsz = pk_fma(oj, splat(up.z), pk_fma(oi, splat(right.z), splat(tl.z)));
+        const v2f ix = pk_rcp(tsx), iy = pk_rcp(tsy), iz = pk_rcp(tsz);
+        // a direction component within 1e-3 of parallel to a slab: its 1/x carries the rounding of ts (up to
+        // ~1e-3 relative here) -> not decided in fp32
+        {
+          const float lim = 1e-6f * T0;     // (1e-3 |tl|)^2
+          const bool par = (tsx.x * tsx.x < lim) | (tsx.y * tsx.y < lim) | (tsy.x * tsy.x < lim) | (tsy.y * tsy.y < lim) |
+                           (tsz.x * tsz.x < lim) | (tsz.y * tsz.y < lim);
+          unc = par ? 3.0e38f : unc;
+        }
 #pragma unroll
         for (int k = 0; k < MAXB; ++k) {
           if (k < nB) {
@@ -180,11 +263,21 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
             tn.y = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
             tf.x = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
             tf.y = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+            {
+              // the ray passes an edge of the box within the slabs' rounding (relative 4e-3 with the 1e-3 limit
+              // above), or a slab root lies at the sample itself (tau = 1): not decided in fp32
+              const bool edge = (fabsf(tf.x - tn.x) <= 4e-3f * (fabsf(tn.x) + fabsf(tf.x))) | (fabsf(tf.y - tn.y) <= 4e-3f * (fabsf(tn.y) + fabsf(tf.y))) |
+                                (fabsf(tn.x - 1.0f) <= 4e-3f) | (fabsf(tn.y - 1.0f) <= 4e-3f) | (fabsf(tf.x - 1.0f) <= 4e-3f) | (fabsf(tf.y - 1.0f) <= 4e-3f);
+              unc = edge ? 3.0e38f : unc;
+            }
             if (LO) {                                                      // see the sphere slow path
               const float lo0 = T_LO * T_LO * raw_rcp(d2.x), lo1 = T_LO * T_LO * raw_rcp(d2.y);   // tau^2 > 4e-12 / |ts|^2
               const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
               const bool a0 = ok0 & in_open(tn.x, 1.0f) & (tn.x * tn.x > lo0), a1 = ok1 & in_open(tn.y, 1.0f) & (tn.y * tn.y > lo1);
               const bool b0 = ok0 & in_open(tf.x, 1.0f) & (tf.x * tf.x > lo0), b1 = ok1 & in_open(tf.y, 1.0f) & (tf.y * tf.y > lo1);
+              const bool nr = (fabsf(tn.x * tn.x - lo0) <= 2e-2f * lo0) | (fabsf(tn.y * tn.y - lo1) <= 2e-2f * lo1) |
+                              (fabsf(tf.x * tf.x - lo0) <= 2e-2f * lo0) | (fabsf(tf.y * tf.y - lo1) <= 2e-2f * lo1);
+              unc = nr ? 3.0e38f : unc;
               if (OPAQUE) { m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1; }
               else {
                 const float ta = pr.tauB[k];
@@ -200,37 +293,55 @@ __device__ __forceinline__ float ls_light_sum(const LsPrims<MAXS, MAXP, MAXB, OP
               const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
               tr.x *= (ok0 & in_open(tn.x, 1.0f)) ? ta : 1.0f; tr.y *= (ok1 & in_open(tn.y, 1.0f)) ? ta : 1.0f;
               tr.x *= (ok0 & in_open(tf.x, 1.0f)) ? ta : 1.0f; tr.y *= (ok1 & in_open(tf.y, 1.0f)) ? ta : 1.0f;
+              ml = min(ml, min(umin3(__float_as_uint(tn.x * d2.x), __float_as_uint(tf.x * d2.x), __float_as_uint(tn.y * d2.y)), __float_as_uint(tf.y * d2.y)));
             }
           }
         }
       }
     }
+    // the smallest positive root of the pair (a crossing at the shadow origin is not decided in fp32);
+    // LO paths compare their roots with the 2e-6 bound themselves
+    if (OPAQUE) { if (!LO) mlow = umin3(mlow, m0, valid1 ? m1 : 0xFFFFFFFFu); }
+    else mlow = min(mlow, ml);
     if (OPAQUE) total += (m0 < __float_as_uint(d2.x) ? 0.0f : 1.0f) + (m1 < __float_as_uint(d2.y) ? 0.0f : 1.0f);
     else total += tr.x + (valid1 ? tr.y : 0.0f);
   }
+  fl.unc = unc; fl.mlow = mlow; fl.dmin = dmin;
   return total;
 }
 
+#ifndef LS_WAVES
+#define LS_WAVES 2
+#endif
 template <int MAXS, int MAXP, int MAXB, bool OPAQUE>
-__global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES))) void k_shade_ls(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                     RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
-                                                    float* __restrict__ fb) {
+                                                    float* __restrict__ fb, FixRec* __restrict__ fix) {
   constexpr int MAXN = MAXS + MAXP + MAXB;
   __shared__ Prim s_prims[MAXN];
   __shared__ float2 s_cells[LS_MAX_CELLS];
   __shared__ float s_lightf[LS_MAX_LIGHTS][LIGHT_STRIDE];    // lights as fp32 (the shadow origin's epsilon lives in cc / num)
   __shared__ float4 s_sphf[MAXS];                             // sphere centres + radii as fp32
+  // low parts: centre = s_sphf + s_sphl, light position = s_lightf[0..2] + s_lightl to ~1e-15; with the hit point split
+  // the same way (pf + pl), oc and tl carry only a few ulp of THEIR size instead of ulps of the coordinates' size
+  __shared__ float4 s_sphl[MAXS];
+  __shared__ float s_lightl[LS_MAX_LIGHTS][4];
   // per light: spheres that (some sample of) the light may be inside of / outside of — hit independent
   __shared__ uint32_t s_lin[LS_MAX_LIGHTS], s_lout[LS_MAX_LIGHTS];
+  // per light: primitives the light's sample square may touch (spheres bit k, planes bit 16+k, boxes bit 24+k): a
+  // crossing at the sample end of a shadow segment (tau = 1) is then possible, which fp32 does not decide
+  __shared__ uint32_t s_lstr[LS_MAX_LIGHTS];
+  __shared__ float s_labs[LS_MAX_LIGHTS];                     // |Lp|_1
   __shared__ double s_matd[LS_MAX_MATS][MAT_STRIDE];
-  // exact fp64 geometry of each lane's hit, parked for the spawn step (hit point, normal, ray direction,
-  // weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
+  // exact fp64 geometry of each lane's hit, parked for the spawn step and the re-test queue (hit point, normal, ray
+  // direction, weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
   __shared__ double s_geo[12][BLOCK];
   __shared__ uint32_t s_wcnt[BLOCK / 64][2];
   __shared__ uint32_t s_base;
   const int n_sh = fp.n_shadow;
   const int n_side = n_sh > 1 ? n_sh : 1;
   const int n_cells = n_side * n_side;
+  const bool brute = fp.brute != 0u;
   {
     const int words = sc.n * (int)(sizeof(Prim) / 16);
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
@@ -238,8 +349,18 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     for (int i = threadIdx.x; i < words; i += BLOCK) dst[i] = src[i];
     for (int i = threadIdx.x; i < sc.nL * LIGHT_STRIDE; i += BLOCK) (&s_lightf[0][0])[i] = (float)sc.lights[i];
     for (int i = threadIdx.x; i < MAXS; i += BLOCK) {
-      s_sphf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (i < sc.nS) s_sphf[i] = make_float4((float)sc.prims[i].a[0], (float)sc.prims[i].a[1], (float)sc.prims[i].a[2], (float)sc.prims[i].a[3]);
+      s_sphf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_sphl[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (i < sc.nS) {
+        const double* a = sc.prims[i].a;
+        const float4 h = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
+        s_sphf[i] = h;
+        s_sphl[i] = make_float4((float)(a[0] - (double)h.x), (float)(a[1] - (double)h.y), (float)(a[2] - (double)h.z), 0.0f);
+      }
+    }
+    for (int i = threadIdx.x; i < sc.nL * 3; i += BLOCK) {
+      const int li = i / 3, c = i - li * 3;
+      const double v_ = sc.lights[LIGHT_STRIDE * li + c];
+      s_lightl[li][c] = (float)(v_ - (double)(float)v_);
     }
     for (int i = threadIdx.x; i < sc.nM * MAT_STRIDE; i += BLOCK) (&s_matd[0][0])[i] = sc.mats[i];
     // per-light table of cell base offsets: -radius/2 + cell*(i or j)   (ray_tracer.py:215, 224-225)
@@ -251,17 +372,35 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       s_cells[e] = n_sh > 1 ? make_float2(fmaf(cell, (float)i, half), fmaf(cell, (float)j, half)) : make_float2(0.0f, 0.0f);
     }
     for (int li = threadIdx.x; li < sc.nL; li += BLOCK) {
-      const float RL = n_sh > 1 ? 0.7072f * (float)sc.lights[LIGHT_STRIDE * li + 8] * 1.001f : 0.0f;
-      uint32_t in_ = 0u, out_ = 0u;
+      const double* L = sc.lights + LIGHT_STRIDE * li;
+      const float RL = n_sh > 1 ? 0.7072f * (float)L[8] * 1.001f : 0.0f;
+      const float labs = (float)(fabs(L[0]) + fabs(L[1]) + fabs(L[2]));
+      const double RS = (double)RL + 1e-4 * (1.0 + labs);        // reach of the sample square + slack (see `far` in the light loop)
+      uint32_t in_ = 0u, out_ = 0u, str_ = 0u;
       for (int k = 0; k < sc.nS && k < MAXS; ++k) {
-        const double dx = sc.lights[LIGHT_STRIDE * li] - sc.prims[k].a[0], dy = sc.lights[LIGHT_STRIDE * li + 1] - sc.prims[k].a[1],
-                     dz = sc.lights[LIGHT_STRIDE * li + 2] - sc.prims[k].a[2];
-        const float l2 = (float)((dx * dx + dy * dy) + dz * dz), r = (float)sc.prims[k].a[3];
+        const double dx = L[0] - sc.prims[k].a[0], dy = L[1] - sc.prims[k].a[1], dz = L[2] - sc.prims[k].a[2];
+        const double l2d = (dx * dx + dy * dy) + dz * dz;
+        const float l2 = (float)l2d, r = (float)sc.prims[k].a[3];
         const float rin = fmaxf(r - RL, 0.0f);
         if (l2 < (r + RL) * (r + RL) * 1.001f) in_ |= 1u << k;
         if (l2 > rin * rin * 0.999f) out_ |= 1u << k;
+        if (fabs(sqrt(l2d) - sc.prims[k].a[3]) <= RS * (1.0 + 1e-5 * sc.prims[k].a[3])) str_ |= 1u << k;
       }
-      s_lin[li] = in_; s_lout[li] = out_;
+      for (int k = 0; k < sc.nP && k < MAXP; ++k) {
+        const Prim& pl = sc.prims[sc.nS + k];
+        if (fabs(((L[0] * pl.a[0] + L[1] * pl.a[1]) + L[2] * pl.a[2]) - pl.a[3]) <= RS * (1.0 + 1e-5 * fabs(pl.a[3]))) str_ |= 0x10000u << k;
+      }
+      for (int k = 0; k < sc.nB && k < MAXB; ++k) {
+        const Prim& b = sc.prims[sc.nS + sc.nP + k];
+        bool in_big = true, in_small = true;
+        for (int ax = 0; ax < 3; ++ax) {
+          const double g = RS * (1.0 + 1e-5 * (fabs(b.a[ax]) + fabs(b.a[3 + ax])));
+          in_big &= (L[ax] >= b.a[ax] - g) & (L[ax] <= b.a[3 + ax] + g);
+          in_small &= (L[ax] > b.a[ax] + g) & (L[ax] < b.a[3 + ax] - g);
+        }
+        if (in_big && !in_small) str_ |= 0x1000000u << k;
+      }
+      s_lin[li] = in_; s_lout[li] = out_; s_lstr[li] = str_; s_labs[li] = labs;
     }
     __syncthreads();
   }
@@ -275,28 +414,37 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
   const float inv_cells = 1.0f / (float)n_cells;
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+  const uint32_t all_prims = ((1u << nS) - 1u) | (((1u << nP) - 1u) << 16);
 
   // Blocks take 256-hit chunks from a device counter (Counters::work_shade, zeroed per frame): chunk costs
   // differ by several x (penumbra vs fully lit), and with a fraction of a frame per GPU there are only a
   // few chunks per resident block, so a static round-robin leaves a long tail.
   __shared__ uint32_t s_iter;
+  // RT_DEBUG_STATS bit 1 << 20 (audit build): wave cycles per phase -> Counters::dbg (hit setup, light setup, sample loops, all)
+  const bool prof = (RT_DBG(fp) & (1u << 20)) != 0u;
+  long long ck_hit = 0, ck_setup = 0, ck_loop = 0, ck_sync = 0;
+  const long long ck_begin = prof ? clock64() : 0;
   for (;;) {
+    const long long ck_s0 = prof ? clock64() : 0;
     if (threadIdx.x == 0) s_iter = atomicAdd(&C->work_shade[level], 1u);
     __syncthreads();
     const uint32_t iter = s_iter;
     __syncthreads();                       // everyone has read s_iter before thread 0 overwrites it
+    if (prof) ck_sync += clock64() - ck_s0;
     if (iter >= n_iters) break;
     const uint32_t h = iter * BLOCK + threadIdx.x;
     const bool active = h < count;
+    long long ck_t = prof ? clock64() : 0;
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
-    float a_cc[MAXS], a_A[MAXS], a_B[MAXS], a_C[MAXS], a_sgn[MAXS], a_tauS[MAXS];
-    float a_num[MAXP], a_D0[MAXP], a_D1[MAXP], a_D2[MAXP], a_tauP[MAXP];
+    v2f a_AB[MAXS], a_Cc[MAXS], a_Sg[(MAXS + 1) / 2];
+    float a_tauS[MAXS];
+    v2f a_D01[MAXP], a_D2n[MAXP];
+    float a_tauP[MAXP];
     float a_blo[MAXB > 0 ? MAXB : 1][3], a_bhi[MAXB > 0 ? MAXB : 1][3], a_tauB[MAXB > 0 ? MAXB : 1];
     bool a_binside[MAXB > 0 ? MAXB : 1];
-    const LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_cc, a_A, a_B, a_C, a_sgn, a_tauS, a_num, a_D0, a_D1, a_D2, a_tauP,
-                                               a_blo, a_bhi, a_tauB, a_binside};
+    LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_AB, a_Cc, a_Sg, a_tauS, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
     d3 p = mk3(0, 0, 0);
-    f3 pf = mkf(0, 0, 0);
+    f3 pf = mkf(0, 0, 0), pl = mkf(0, 0, 0);
     f3 nf = mkf(0, 0, 1), v = mkf(0, 0, 1), wgt = mkf(0, 0, 0);
     int mat_idx = 0, own = -1;
     bool own_is_plane = false;
@@ -314,35 +462,46 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       lp = r.lp; gpix = global_pixel(fp.rs, lp);
       wgt = tof(r.w);
       pf = tof(p);
+      pl = mkf((float)(p.x - (double)pf.x), (float)(p.y - (double)pf.y), (float)(p.z - (double)pf.z));
+      const uint32_t t_ = threadIdx.x;
+      s_geo[0][t_] = hp.x; s_geo[1][t_] = hp.y; s_geo[2][t_] = hp.z;
+      s_geo[3][t_] = n.x; s_geo[4][t_] = n.y; s_geo[5][t_] = n.z;
       if (spawn_level) {
-        const uint32_t t_ = threadIdx.x;
-        s_geo[0][t_] = hp.x; s_geo[1][t_] = hp.y; s_geo[2][t_] = hp.z;
-        s_geo[3][t_] = n.x; s_geo[4][t_] = n.y; s_geo[5][t_] = n.z;
         s_geo[6][t_] = r.d.x; s_geo[7][t_] = r.d.y; s_geo[8][t_] = r.d.z;
         s_geo[9][t_] = r.w.x; s_geo[10][t_] = r.w.y; s_geo[11][t_] = r.w.z;
       }
     }
     bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
     uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
+    float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
+    float a_sgn[MAXS];
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
-      a_cc[k] = 1.0f; a_sgn[k] = -1.0f;
+      a_Cc[k] = mk2(0.0f, 1.0f); a_sgn[k] = -1.0f; a_AB[k] = mk2(0.0f, 0.0f);
       if (k < nS) {
         const Prim& s_ = P[k];
         const double ox = p.x - s_.a[0], oy = p.y - s_.a[1], oz = p.z - s_.a[2];
-        a_cc[k] = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
-        a_sgn[k] = a_cc[k] < 0.0f ? 1.0f : -1.0f;
-        near_scene &= fabsf(a_cc[k]) < 1000.0f * (float)s_.a[4];
-        if (own == k) { own_in_bit = a_cc[k] < 0.0f ? 1u << k : 0u; own_out_bit = a_cc[k] < 0.0f ? 0u : 1u << k; }
+        const float cc = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
+        a_Cc[k].y = cc;
+        // far root iff the origin is inside — and for the hit's OWN sphere seen from outside: the near root of a ray that
+        // re-enters it is the crossing at the shadow origin itself (t' = 1e-6/cos, which the reference may or may not
+        // see); the far root decides, as in the reference, unless the light is inside the sphere (LO path)
+        a_sgn[k] = (cc < 0.0f || own == k) ? 1.0f : -1.0f;
+        near_scene &= fabsf(cc) < 1000.0f * (float)s_.a[4];
+        oc2max = fmaxf(oc2max, cc + (float)s_.a[4]);
+        if (own == k) { own_in_bit = cc < 0.0f ? 1u << k : 0u; own_out_bit = cc < 0.0f ? 0u : 1u << k; }
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
+    static_assert(MAXS % 2 == 0, "root signs are stored as pairs");
+#pragma unroll
+    for (int k = 0; k < MAXS / 2; ++k) a_Sg[k] = mk2(a_sgn[2 * k], a_sgn[2 * k + 1]);
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
-      a_num[k] = 0.0f;
+      a_D2n[k] = mk2(0.0f, 0.0f); a_D01[k] = mk2(0.0f, 0.0f);
       if (k < nP) {
         const Prim& s_ = P[nS + k];
-        a_num[k] = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
+        a_D2n[k].y = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
         a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -362,6 +521,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     const float kd0 = (float)mat[0], kd1 = (float)mat[1], kd2 = (float)mat[2];
     const float ks0 = (float)mat[3], ks1 = (float)mat[4], ks2 = (float)mat[5];
     const float shin = (float)mat[9];
+    const float one_m = 1.0f - (float)mat[10];
+    // magnitude for the error bounds (LsTol): largest |oc|
+    const float ocm = raw_sqrt(fmaxf(oc2max, 0.0f)) * 1.0001f;
 
     // ----------------------------------- wave-level pre-cull of (light, sphere) pairs ----------
     // A wave's hits are spatially compact (8x8 pixel tile, or neighbours in the queue).  Bound them by a
@@ -370,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
     // that fail, the per-lane coefficient / culling arithmetic below (~45 instructions per sphere) is skipped
     // by wave-uniform branches.  Conservative: a pair is only dropped when no lane's fan can touch it.
     unsigned long long pair_can = ~0ull;
-    if (nS * sc.nL <= 64) {
+    if (nS * sc.nL <= 64 && !brute) {
       float cnt = active ? 1.0f : 0.0f, sx = active ? pf.x : 0.0f, sy = active ? pf.y : 0.0f, sz = active ? pf.z : 0.0f;
 #pragma unroll
       for (int o_ = 32; o_ > 0; o_ >>= 1) {
@@ -401,11 +563,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       pair_can = __ballot(may);
     }
 
+    if (prof) { const long long t = clock64(); ck_hit += t - ck_t; ck_t = t; }
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
     for (int li = 0; li < sc.nL; ++li) {
+      // (compiler barrier: without it the block-invariant LDS reads of the light loop — sphere centres, plane
+      // normals — are hoisted out of the chunk loop into ~40 long-lived VGPRs, which costs the second wave per SIMD)
+      asm volatile("" ::: "memory");
       const float* lg = s_lightf[li];
-      const f3 tl = mkf(lg[0] - pf.x, lg[1] - pf.y, lg[2] - pf.z);
+      const float* ll = s_lightl[li];
+      const f3 tl = mkf((lg[0] - pf.x) + (ll[0] - pl.x), (lg[1] - pf.y) + (ll[1] - pl.y), (lg[2] - pf.z) + (ll[2] - pl.z));
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
@@ -416,23 +583,23 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       const float radius = lg[8];
       const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
       const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
-      const uint32_t wcan = nS * sc.nL <= 64 ? (uint32_t)(pair_can >> (li * nS)) : 0xFFFFFFFFu;   // spheres this wave may touch
+      const uint32_t wcan = (nS * sc.nL <= 64 && !brute) ? (uint32_t)(pair_can >> (li * nS)) : 0xFFFFFFFFu;   // spheres this wave may touch
 #pragma unroll
       for (int k = 0; k < MAXS; ++k) {
-        a_A[k] = a_B[k] = a_C[k] = 0.0f;
+        a_AB[k] = mk2(0.0f, 0.0f); a_Cc[k].x = 0.0f;
         if (k < nS && ((wcan >> k) & 1u)) {
-          const float4 sf = s_sphf[k];
-          const f3 oc = mkf(pf.x - sf.x, pf.y - sf.y, pf.z - sf.z);
-          a_A[k] = dotf(oc, tl); a_B[k] = dotf(oc, right); a_C[k] = dotf(oc, up);
+          const float4 sf = s_sphf[k], sl = s_sphl[k];
+          const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
+          a_AB[k] = mk2(dotf(oc, tl), dotf(oc, right)); a_Cc[k].x = dotf(oc, up);
         }
       }
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
-        a_D0[k] = a_D1[k] = a_D2[k] = 0.0f;
+        a_D01[k] = mk2(0.0f, 0.0f); a_D2n[k].x = 0.0f;
         if (k < nP) {
           const Prim& s_ = P[nS + k];
           const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
-          a_D0[k] = dotf(N, tl); a_D1[k] = dotf(N, right); a_D2[k] = dotf(N, up);
+          a_D01[k] = mk2(dotf(N, tl), dotf(N, right)); a_D2n[k].x = dotf(N, up);
         }
       }
       // Slow path (exact lower bound 2e-6 on every crossing) only if some lane needs it: the light is
@@ -451,11 +618,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       uint32_t act = 0;
       bool lane_can = false;     // some primitive may cross some shadow segment of this lane
       bool lane_full = false;    // opaque scenes: one sphere certainly blocks EVERY sample of this lane
+      const float RL = 0.7072f * radius * 1.001f;
       {
         // Sphere k can cross the segment p -> S of some sample S only if, for some tau in [0,1],
         // |oc + tau*tl| <= r + tau*RL (the segments to all samples fan out inside a cone around
         // p -> Lp):  g(tau) = tau^2 (T0 - RL^2) + 2 tau (A - r RL) + cc <= 0, minimised on [0,1].
-        const float RL = 0.7072f * radius * 1.001f;
         const float qa = T0 - RL * RL, rqa = raw_rcp(qa);
         const float rT0 = rl * rl;                                             // 1 / |tl|^2
         const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
@@ -463,25 +630,26 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
         for (int k = 0; k < MAXS; ++k) {
           if (k < nS && ((wcan >> k) & 1u)) {
             const float r = s_sphf[k].w;
-            const float qb = a_A[k] - r * RL;
+            const float A_ = a_AB[k].x, B_ = a_AB[k].y, C_ = a_Cc[k].x, cc_ = a_Cc[k].y;
+            const float qb = A_ - r * RL;
             const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
-            const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), a_cc[k]);
+            const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), cc_);
             // origin outside the sphere and every sample direction leaves it (oc.ts > 0 for all samples):
             // both roots are <= 0 — the lit side of the hit's own sphere, spheres behind the hit
-            const float bt_lo = a_A[k] - hw * (fabsf(a_B[k]) + fabsf(a_C[k]));
-            const bool away = (a_cc[k] >= 0.0f) & (bt_lo > 1e-5f * (fabsf(a_A[k]) + 1e-3f));
-            const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(a_cc[k]) + r * r))) & !away;
+            const float bt_lo = A_ - hw * (fabsf(B_) + fabsf(C_));
+            const bool away = (cc_ >= 0.0f) & (bt_lo > 1e-5f * (fabsf(A_) + 1e-3f));
+            const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc_) + r * r))) & !away;
             lane_can |= can;
             if (__any(active & can)) act |= 1u << k;
             if (OPAQUE) {
               // Umbra: at the parameter ts of closest approach of the central segment, the whole fan
               // cross-section (radius ts*RL around p + ts*tl) lies inside the sphere while p is outside
               // it -> every segment p -> S enters the sphere at a parameter in (0, ts), ts < 1.
-              const float ts = fminf(fmaxf(-a_A[k] * rT0, 0.0f), 1.0f);
-              const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * a_A[k]), a_cc[k] + r * r);     // |oc + ts*tl|^2
+              const float ts = fminf(fmaxf(-A_ * rT0, 0.0f), 1.0f);
+              const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * A_), cc_ + r * r);     // |oc + ts*tl|^2
               // fp32 cancellation bound of dist2 (hits far from the scene: |oc|^2 ~ T0 >> r^2 -> no claim)
               const float room = r * 0.999f - ts * RL;
-              lane_full |= (a_cc[k] > 0.0f) & (room > 0.0f) & (dist2 < room * room);
+              lane_full |= (cc_ > 0.0f) & (room > 0.0f) & (dist2 < room * room);
             }
           }
         }
@@ -502,36 +670,74 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
           if (k < nP) {
-            const float spread = hw * (fabsf(a_D1[k]) + fabsf(a_D2[k])) + 1e-6f * fabsf(a_D0[k]);
+            const float D0_ = a_D01[k].x, num_ = a_D2n[k].y;
+            const float spread = hw * (fabsf(a_D01[k].y) + fabsf(a_D2n[k].x)) + 1e-6f * fabsf(D0_);
             // tau = num / den in (0, 1) needs num and den of the same sign
-            const bool can = a_num[k] < 0.0f ? (a_D0[k] - spread <= 0.0f) : (a_num[k] > 0.0f ? (a_D0[k] + spread >= 0.0f) : true);
+            const bool can = num_ < 0.0f ? (D0_ - spread <= 0.0f) : (num_ > 0.0f ? (D0_ + spread >= 0.0f) : true);
             lane_can |= can;
             if (__any(active & can)) act |= 0x10000u << k;
           }
         }
         if (MAXB > 0) lane_can |= nB > 0;
       }
+      if (brute) { act = all_prims; lane_can = true; lane_full = false; }
+      if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
       const float2* cells = s_cells + li * n_cells;
       float total;
+      bool undecided = false;      // this (hit, light) goes to the exact re-test (k_fix_exact) with T = 0 here
       if (RT_DBG(fp) & 8u) act = 0xFFFFFFFFu;
-      if (!(RT_DBG(fp) & 2u) && !__any(active & lane_can & !lane_full)) {
+      uint32_t str_act = act & s_lstr[li];
+      if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
+      if (!brute && !(RT_DBG(fp) & 2u) && !__any(active & lane_can & !lane_full)) {
         // No lane of the wave has a penumbra candidate for this light: every lane is either fully lit
         // (all n^2 terms are exactly 1) or in the umbra of one opaque sphere (all terms exactly 0).
         total = lane_full ? 0.0f : (float)n_cells;
-        if (RT_DBG(fp) && lane == 0) atomicAdd(&C->queries, 1ull);
-      } else if ((RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true)))
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
-                                                                   T0, T1, T2, own);
-      else
-        total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
-                                                                    T0, T1, T2);
-      if (RT_DBG(fp) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
+        if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull);
+      } else if (str_act != 0u) {
+        // the light's sample square touches a candidate primitive: crossings at the sample end of a segment
+        total = 0.0f; undecided = true;
+      } else {
+        // fp32 error bounds of this (hit, light): see LsTol.  |ts| <= tsm, |oc| <= ocm.  oc and tl carry <= 2 ulp of
+        // their size (two-part subtraction above), the basis vectors <= 4 ulp per component, the sample offsets
+        // <= 3 ulp of the light's size; the dots accumulate 3 more.  With |oi|, |oj| <= radius/2 (18 radius = 25 RL):
+        //   error of oc.ts          e_b <= u |oc| (9 |ts| + 25 RL)
+        //   relative error of |ts|^2 cc    <= 34 u   (light farther than 3 RL: |ts| within a factor 2 of tsm)
+        //   => |disc error| <= |oc.ts| (2 e_b + 34 u |oc| |ts|) + e_b^2 when |disc| is small; all with a factor 1.5
+        LsTol tol;
+        const float tlen = T0 * rl;                                            // |tl|
+        const float tsm = tlen + RL;
+        const float e_b = 1.5f * LS_U * ocm * (9.0f * tsm + 25.0f * RL);
+        tol.kap = 2.0f * e_b + 51.0f * LS_U * ocm * tsm;
+        tol.kap0 = 2.0f * e_b * e_b;
+        tol.elo = 2.0f * T_LO * tsm + 2.0f * (e_b + tol.kap);
+        tol.eden = 12.0f * LS_U * tsm;
+        LsFlags fl = ls_flags_init();
+        if ((RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true)))
+          total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
+                                                                     T0, T1, T2, tol.kap, fl, own);
+        else
+          total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
+                                                                      T0, T1, T2, tol.kap, fl);
+        // also undecided in fp32: the light within 3 sample-square radii of the hit (|ts| is then not comparable
+        // to |tl|, which the bounds assume), the 0.9 switch of the basis (ray_tracer.py:202-205) within rounding
+        // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
+        const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
+        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f) | !(T0 > 1e-12f) | far;
+      }
+      if (prof) { const long long t = clock64(); ck_loop += t - ck_t; ck_t = t; }
+      if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
       if ((RT_DBG(fp) & 2u) && active) {      // shortcut disabled: audit what it would have claimed
         if (!lane_can && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
         if (lane_full && total != 0.0f) atomicAdd(&C->dbg[1], 1ull);
         if (lane_can && !lane_full) atomicAdd(&C->dbg[2], 1ull);
         atomicAdd(&C->dbg[3], 1ull);
       }
+      // the conservative claims are exact whatever the loop computed for the lane: nothing can cross any of its
+      // segments (all terms 1) / one opaque sphere swallows its whole fan (all terms 0)
+      if (!lane_can) { total = (float)n_cells; undecided = false; }
+      if (OPAQUE && lane_full) { total = 0.0f; undecided = false; }
+      undecided &= active;
+      if (undecided) total = 0.0f;
       const float T = total * inv_cells;
       const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
@@ -550,11 +756,18 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       spc0 = fmaf(ks0 * lg[3], s2, spc0);
       spc1 = fmaf(ks1 * lg[4], s2, spc1);
       spc2 = fmaf(ks2 * lg[5], s2, spc2);
+      if (__any(undecided)) {
+        // colour per unit of T of this (hit, light): d(colour)/dI * shadow_intensity, times weight and (1 - transparency)
+        const float cm = lg[7] * one_m, sp = pw * lg[6];
+        const uint32_t t_ = threadIdx.x;
+        const d3 pe = mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS);
+        queue_fix(undecided, fix, C, fp, pe, wgt.x * cm * lg[3] * fmaf(kd0, ndl, ks0 * sp), wgt.y * cm * lg[4] * fmaf(kd1, ndl, ks1 * sp),
+                  wgt.z * cm * lg[5] * fmaf(kd2, ndl, ks2 * sp), lp, gpix, level, li);
+      }
     }
 
     // ------------------------------------------------- phase 3: accumulate, spawn children -----
     if (active) {
-      const float one_m = 1.0f - (float)mat[10];
       float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
       if (seq_background_term(fp, level, mat)) {                             // ray_tracer.py:370-377
         b0 = (float)(sc.bg[0] * mat[10]); b1 = (float)(sc.bg[1] * mat[10]); b2 = (float)(sc.bg[2] * mat[10]);
@@ -565,6 +778,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       if (level == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
       else { atomicAdd(dst + 0, c0); atomicAdd(dst + 1, c1); atomicAdd(dst + 2, c2); }
     }
+    const long long ck_s1 = prof ? clock64() : 0;
     if (spawn_level) {                                                     // ray_tracer.py:565-595
       const bool needT = active && (mat[10] > EPS);
       const bool needR = active && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS);
@@ -608,6 +822,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
       }
       __syncthreads();   // s_wcnt / s_base are reused by the next iteration
     }
+    if (prof) ck_sync += clock64() - ck_s1;
+  }
+  if (prof && lane == 0) {
+    atomicAdd(&C->queries, (unsigned long long)ck_sync);
+    atomicAdd(&C->dbg[0], (unsigned long long)ck_hit); atomicAdd(&C->dbg[1], (unsigned long long)ck_setup);
+    atomicAdd(&C->dbg[2], (unsigned long long)ck_loop); atomicAdd(&C->dbg[3], (unsigned long long)(clock64() - ck_begin));
   }
 }
 
@@ -615,16 +835,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade_ls(DevScene sc, DevCamera cam, 
 // Scenes served: up to 6 spheres + 2 planes without boxes, or up to 4 spheres + 2 planes + 4 boxes,
 // any shadow grid with lights * n^2 <= LS_MAX_CELLS.  Returns false -> caller uses another kernel.
 static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
-                            RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, int grid,
+                            RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
                             hipStream_t st) {
   const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
   if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
-                                   cur, nxt, hits, C, fb);                                                           \
+                                   cur, nxt, hits, C, fb, fix);                                                      \
     else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur,  \
-                            nxt, hits, C, fb);                                                                       \
+                            nxt, hits, C, fb, fix);                                                                  \
     return true;                                                                                                    \
   } while (0)
   if (ds.nB == 0) {

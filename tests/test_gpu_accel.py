@@ -72,7 +72,7 @@ def test_render_large_scene_fp64_and_fp32(oracle, n_sph, n_box, W, H):
     img32 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 21), precision="fp32", verbose=False)
     d8 = np.abs(_q(img32) - _q(ref))
     print(f"{n_sph} spheres + {n_box} boxes {W}x{H} fp32: max 8-bit diff {d8.max()}, channels > 1 level {(d8 > 1).sum()} of {d8.size}")
-    assert (d8 <= 1).mean() >= 0.995
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level"
 
 
 def test_hierarchy_equals_brute_force_mode():
@@ -164,7 +164,7 @@ def test_far_hits_keep_the_culling_conservative():
     ref = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 3), verbose=False)
     err_accel, err_brute = np.abs(out["1"] - ref), np.abs(out["0"] - ref)
     assert (err_accel <= err_brute + 2e-6).all()
-    assert (np.abs(_q(out["1"]) - _q(ref)) <= 1).mean() >= 0.995
+    assert np.abs(_q(out["1"]) - _q(ref)).max() <= 1
     far_row = H // 2 - 1
     print(f"far row: max |fp32 - fp64| culled {err_accel[far_row].max():.2e}, brute force {err_brute[far_row].max():.2e}")
 
@@ -186,4 +186,4 @@ def test_hierarchy_larger_than_the_lds_staging(oracle):
     for k in ("rays", "hits", "shadow_rays", "segments"):
         assert stats[k] == ost[k], k
     assert rel_err(img, ref).max() < 1e-12
-    assert (np.abs(_q(img32) - _q(ref)) <= 1).mean() >= 0.995
+    assert np.abs(_q(img32) - _q(ref)).max() <= 1

@@ -58,7 +58,7 @@ def test_ragged_sizes(oracle, W, H):
     img, ref, stats, ostats = _both(text, W, H, oracle)
     assert rel_err(img, ref).max() < 1e-12 and stats["rays"] == ostats["rays"]
     img32, ref, *_ = _both(text, W, H, oracle, "fp32")
-    assert (np.abs(_q(img32) - _q(ref)) <= 1).mean() >= 0.99
+    assert np.abs(_q(img32) - _q(ref)).max() <= 1
 
 
 def test_queue_overflow_regrows_and_matches_oracle(oracle):
@@ -73,7 +73,7 @@ def test_queue_overflow_regrows_and_matches_oracle(oracle):
     assert stats["rays"] == ostats["rays"] and stats["hits"] == ostats["hits"]
     assert rel_err(img, ref).max() < 1e-9
     img32, ref, *_ = _both(text, 48, 32, oracle, "fp32")
-    assert (np.abs(_q(img32) - _q(ref)) <= 1).mean() >= 0.99
+    assert np.abs(_q(img32) - _q(ref)).max() <= 1
 
 
 def test_light_below_the_floor_and_inside_a_sphere(oracle):
@@ -88,7 +88,7 @@ def test_light_below_the_floor_and_inside_a_sphere(oracle):
     img32, ref, *_ = _both(text, 96, 64, oracle, "fp32")
     d8 = np.abs(_q(img32) - _q(ref))
     print(f"light-behind-surface scene fp32: max 8-bit diff {d8.max()}, channels > 1 level {(d8 > 1).sum()} of {d8.size}")
-    assert (d8 <= 1).mean() >= 0.995
+    assert d8.max() <= 1
 
 
 def test_scene_outside_small_kernel_limits_uses_general_kernel(oracle):
@@ -108,7 +108,7 @@ def test_scene_outside_small_kernel_limits_uses_general_kernel(oracle):
     assert rel_err(img, ref).max() < 1e-9
     img32, ref, *_ = _both(text, 64, 40, oracle, "fp32")
     d8 = np.abs(_q(img32) - _q(ref))
-    assert (d8 <= 1).mean() >= 0.995
+    assert d8.max() <= 1
 
 
 def test_numpy_stream_jitter_on_overflow_scene(oracle):

@@ -43,9 +43,8 @@ def test_pool_4k_fp32_against_fp64_and_counts(pool4k):
         assert sa[k] == sb[k], k
     assert abs(sa["rays"] / (W * H) - 1.585) < 0.01 and abs(sa["shadow_rays"] / (W * H) - 165.4) < 1.0
     d8 = np.abs(_q(a) - _q(b))
-    frac = (d8 <= 1).mean()
     print(f"pool 4K fp32 vs fp64: max 8-bit diff {d8.max()}, channels > 1 level {(d8 > 1).sum()} of {d8.size}")
-    assert frac >= 0.999
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level"
     assert np.abs(a.astype(np.float64) - b).mean() < 1e-5
 
 

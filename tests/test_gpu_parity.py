@@ -143,12 +143,11 @@ def test_fp32_image_within_one_8bit_level(rt, name):
     img = rt.render_hip(cam, st, mats, surfs, lights, W, H, precision="fp32", jitter=("pixel", int(g["seed"])), verbose=False)
     ref = g["image_B"]
     d8 = np.abs(quant(img) - quant(ref))
-    # north_star fp32 bar: <= 1/255 per 8-bit channel.  A shadow sample or a silhouette pixel can
-    # flip when a ray grazes a surface within fp32 rounding; such pixels are counted, not hidden.
-    frac_ok = (d8 <= 1).mean()
+    # north_star fp32 bar: <= 1/255 per 8-bit channel, on EVERY channel: shadow samples whose hit / miss decision
+    # lies within the fp32 error bound are re-tested in fp64 (rt_stats.retested), so none can flip.
     print(f"{name}: max 8-bit diff {d8.max()}, channels > 1 level: {(d8 > 1).sum()} of {d8.size}, "
           f"max |linear diff| {np.abs(img - ref).max():.3e}")
-    assert frac_ok >= 0.999
+    assert d8.max() <= 1
     assert np.abs(img - ref).mean() < 2e-4
 
 
@@ -240,5 +239,5 @@ def test_pool_fp32_960x540_vs_oracle(rt, oracle):
     d8 = np.abs(quant(img) - quant(o_img))
     print(f"pool 960x540 fp32: max 8-bit diff {d8.max()}, channels > 1 level: {(d8 > 1).sum()} of {d8.size}, "
           f"mean |linear diff| {np.abs(img - o_img).mean():.3e}")
-    assert (d8 <= 1).mean() >= 0.9995
+    assert d8.max() <= 1
     assert np.abs(img - o_img).mean() < 1e-4

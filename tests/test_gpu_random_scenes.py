@@ -74,7 +74,7 @@ def test_random_scene_fp64_exact_and_fp32_close(oracle, seed, opaque):
     assert rel_err(img, ref).max() < 1e-9, text
     img32 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False)
     d8 = np.abs(_q(img32) - _q(ref))
-    assert (d8 <= 1).mean() >= 0.995, (float((d8 <= 1).mean()), text)
+    assert d8.max() <= 1, (int(d8.max()), int((d8 > 1).sum()), text)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -111,4 +111,4 @@ def test_random_large_scene_through_the_hierarchy(oracle, seed):
     assert rel_err(img, ref).max() < 1e-9
     img32 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False)
     d8 = np.abs(_q(img32) - _q(ref))
-    assert (d8 <= 1).mean() >= 0.99, float((d8 <= 1).mean())
+    assert d8.max() <= 1, (int(d8.max()), int((d8 > 1).sum()))

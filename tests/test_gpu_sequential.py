@@ -39,7 +39,7 @@ def test_sequential_fp32_matches_reference_render(name):
                  precision="fp32", verbose=False)
     d8 = np.abs(_q(img) - _q(g["image_B"]))
     print(f"{name}: GPU sequential fp32: max 8-bit diff {d8.max()}, channels > 1 level {(d8 > 1).sum()} of {d8.size}")
-    assert (d8 <= 1).mean() >= 0.995
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level"
 
 
 def test_sequential_fp64_vs_oracle_larger_frame(oracle):

@@ -25,7 +25,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.CameraDesc) == 15 * 8
     assert C.sizeof(_lib.Frame) == 12 * 4
     assert C.sizeof(_lib.SceneDesc) == 8 * 8 + 24
-    assert C.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 2 * 32 * 8 + 3 * 4 + 2 * 4 + 4
+    assert C.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 2 * 32 * 8 + 3 * 4 + 2 * 4 + 4 + 8
 
 
 def test_rows_in_part_matches_library():

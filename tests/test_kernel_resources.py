@@ -29,7 +29,7 @@ def test_headline_kernel_keeps_two_waves_per_simd():
 @pytest.mark.parametrize("kernel,header,args,min_occ", [
     # large-scene shade kernel, 3x3 shadow grid: 2 waves/SIMD (LDS lists + <= 256 VGPRs)
     ("rt::k_shade_fast<9, false, true, false>", "rt_shade_fast.hpp",
-     "(rt::DevScene, rt::DevCamera, rt::FrameParams, int, rt::RayQueue, rt::RayQueue, const rt::HitRec*, rt::Counters*, float*, int)", 2),
+     "(rt::DevScene, rt::DevCamera, rt::FrameParams, int, rt::RayQueue, rt::RayQueue, const rt::HitRec*, rt::Counters*, float*, int, rt::FixRec*)", 2),
     # large-scene trace kernel: four workgroups per CU (nodes + hit staging + wave lists <= 40 KiB, <= 128 VGPRs);
     # the hierarchy walk is a latency chain, 3 -> 4 waves/SIMD was worth 14 %
     ("rt::k_trace<float, false>", "rt_kernels.hpp",
