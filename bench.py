@@ -75,6 +75,9 @@ def cpu_baseline(name, gs, cam, st, mats, surfs, lights, W, H, precision):
                       f"1 frame, {rays} rays in {dt:.2f} s, C oracle with OpenMP"}
     parity = {"sample": f"{w}x{h}", "max_8bit_diff": int(d8.max()), "channels_gt_1_level": int((d8 > 1).sum()),
               "channels": int(d8.size), "max_rel_err": rel}
+    # the reference's own figure, measured in the build container (the reference cannot travel)
+    base["reference_numpy"] = {"value": 0.763, "unit": "Mrays/s", "cores": 1,
+                               "sample": "pool.txt 500x500 file settings, render_vectorized of the reference itself, 8 vCPU Xeon container"}
     return base, parity
 
 
@@ -91,7 +94,8 @@ def main():
     ap.add_argument("--timing-every", type=int, default=4,
                     help="bracket the kernels of every k-th timed frame with HIP events (the events cost ~3 %% of a 4K frame)")
     ap.add_argument("--prewarm", type=int, default=16, help="untimed setup frames before the warmup steps (workspace growth, clock ramp)")
-    ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with a full-frame render on rank 0")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the comparison of the gathered frame with a full-frame render on rank 0 (outside the timed region)")
+    ap.add_argument("--brute-frames", type=int, default=3, help="fp32, N = 1: frames rendered with RT_FLAG_BRUTE_FORCE after the timed region for roofline.frac (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -141,7 +145,13 @@ def main():
     cam.setup(W / H)
     packed = pack_scene(mats, surfs, lights, st.background_color)
     gs = GpuScene(packed, device=local_rank)
-    gs.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels, gather and events share one stream
+    # The library renders on a stream of its own unless it is given one (rt_scene_set_stream; NULL = its private
+    # non-blocking stream, which torch's default stream does NOT order against).  N = 1 needs no sharing: the timed
+    # region ends with a device-wide synchronize.  N > 1: the render and the gather run on ONE explicit torch stream
+    # (or on two with events between them when pipelined), so the gather can never read a half-rendered tile.
+    serial_stream = torch.cuda.Stream(dev) if world > 1 else None
+    if serial_stream is not None:
+        gs.set_stream(serial_stream.cuda_stream)
 
     tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
     dtype = torch.float32 if precision == "fp32" else torch.float64
@@ -177,7 +187,8 @@ def main():
             gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
                       part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
             if world > 1:
-                gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+                with torch.cuda.stream(serial_stream):      # same stream as the kernels: ordered after them
+                    gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             return
         b = k & 1
         render_stream = render_streams[b]
@@ -228,12 +239,12 @@ def main():
         rays, hits, shadow = float(last.rays), float(last.hits), float(last.shadow_rays)
 
     verify = None
-    if args.verify and world > 1 and rank == 0:
+    if not args.no_verify and world > 1 and rank == 0:
         full = torch.empty((H, W, 3), dtype=dtype, device=dev)
         torch.cuda.synchronize()
         gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=full.data_ptr())
         torch.cuda.synchronize()
-        verify = {"max_abs_diff_vs_single_gpu_frame": float((full - frame).abs().max())}
+        verify = {"max_abs_diff_vs_single_gpu_frame": float((full - frame).abs().max()), "ranks": dist.get_world_size(), "backend": backend}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -250,9 +261,31 @@ def main():
                                          hits=int(last.hits), segments=seg)
         roofline = None
         if shade_ms > 0:
-            achieved = flops_frame / (shade_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[precision]
+            effective = flops_frame / (shade_ms * 1e-3) / 1e12
+            small = n_pln <= 2 and ((n_box == 0 and n_sph <= 6) or (0 < n_box <= 4 and n_sph <= 4))
+            kernel = (("k_shade_ls" if small else "k_shade_fast") if precision == "fp32" else "k_shade_exact")
+            # fp32: the frame's shade kernels skip most of the flop model's work (conservative culling, fully-lit / umbra
+            # shortcuts), so model flops / their time is an EFFECTIVE rate that can exceed the peak.  The roofline fraction
+            # is therefore measured on frames rendered with RT_FLAG_BRUTE_FORCE (same kernels, every surface tested for every
+            # shadow sample = the work the flop model counts), outside the timed region.
+            brute = None
+            if precision == "fp32" and world == 1 and args.brute_frames > 0:
+                bs = []
+                for _ in range(args.brute_frames + 1):
+                    st_b = _lib.Stats()
+                    gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=tile.data_ptr(),
+                              flags=_lib.RT_FLAG_TIMING | _lib.RT_FLAG_BRUTE_FORCE, stats=st_b)
+                    bs.append(st_b)
+                bs = bs[1:]                                   # first one: warm-up
+                b_shade = sum(x.shade_ms for x in bs) / len(bs); b_total = sum(x.total_ms for x in bs) / len(bs)
+                b_launches = max(bs[0].shade_launches, 1)
+                b_ach = flops_frame / (b_shade * 1e-3) / 1e12
+                brute = {"frames": len(bs), "frame_ms": round(b_total, 4), "shade_ms": round(b_shade, 4), "launch_ms": b_shade / b_launches,
+                         "launches_per_frame": b_launches, "achieved": round(b_ach, 3), "frac": round(b_ach / peak, 4),
+                         "rays_equal": int(bs[0].rays) == int(last.rays) and int(bs[0].hits) == int(last.hits)}
             traffic = None
-            executed = None      # counted flops of the same launches from the committed PMC pass (profiles/)
+            executed = None      # counted instructions / flops of the same launches from the committed PMC pass (profiles/)
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
@@ -260,22 +293,32 @@ def main():
                     traffic = rec.get("hbm_bytes_per_shade_launch")
                     if world == 1 and rec.get("executed_fp32_flops_per_frame"):
                         ex = rec["executed_fp32_flops_per_frame"] / (shade_ms * 1e-3) / 1e12
-                        executed = {"tflops": round(ex, 2), "frac": round(ex / PEAK_TFLOPS[precision], 4),
+                        executed = {"tflops": round(ex, 2), "frac": round(ex / peak, 4),
                                     "valu_wave_instructions_per_frame": rec.get("valu_wave_instructions_per_frame"),
+                                    "valu_issue_fraction_of_measured_peak": rec.get("valu_issue_fraction_of_measured_peak"),
                                     "valu_active_fraction_of_wave_cycles": rec.get("valu_active_fraction_of_wave_cycles"),
-                                    "waves_per_simd": rec.get("waves_per_simd"),
-                                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU_*_F32, packed halves uncounted)"}
+                                    "waves_per_simd": rec.get("waves_per_simd"), "round": rec.get("round"),
+                                    "source": rec.get("source", "profiles/pmc_latest.json (rocprofv3 --pmc)")}
                 except Exception:
                     traffic = None
-            small = n_pln <= 2 and ((n_box == 0 and n_sph <= 6) or (0 < n_box <= 4 and n_sph <= 4))
-            roofline = {"bound": "valu", "kernel": (("k_shade_ls" if small else "k_shade_fast") if precision == "fp32" else "k_shade_exact"),
-                        "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d) (every query tests every surface); the kernels' "
-                                      "conservative culling skips part of that work, so achieved is an effective rate",
-                        "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_TFLOPS[precision], 4), "traffic": traffic, "executed": executed,
-                        "flops_per_launch": flops_frame / launches, "launch_ms": shade_ms / launches,
-                        "launches_per_step": launches, "frames_with_events": len(timed), "shade_ms_per_step": round(shade_ms, 4),
+            culled = {"shade_ms_per_step": round(shade_ms, 4), "launch_ms": shade_ms / launches, "launches_per_step": launches,
+                      "effective_tflops": round(effective, 3), "effective_frac": round(effective / peak, 4),
+                      "note": "model flops / time of the culled kernels: useful work per second, not utilisation (can exceed 1)"}
+            if brute is not None:
+                achieved, frac, basis = brute["achieved"], brute["frac"], "brute_force"
+            elif precision == "fp64":
+                # k_shade_exact's only skipped work is fan_cull's candidate sets; no brute-force switch exists for it
+                achieved, frac, basis = round(effective, 3), round(effective / peak, 4), "culled (fp64 kernel: effective rate)"
+            else:
+                achieved, frac, basis = None, None, "not measured (N > 1 or --brute-frames 0)"
+            roofline = {"bound": "valu", "kernel": kernel,
+                        "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d): every query tests every surface",
+                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac, "frac_basis": basis,
+                        "traffic": traffic, "brute_force": brute, "culled": culled, "executed": executed,
+                        "flops_per_launch": flops_frame / launches, "frames_with_events": len(timed),
                         "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
+            if frac is not None and precision == "fp32":
+                assert frac <= 1.0, f"roofline.frac {frac} > 1: the brute-force run did not execute the model's work"
         out = {
             "metric": "Mrays/s incl. shadow+secondary rays, pool.txt 4K" if args.workload == "pool4k"
                       else f"Mrays/s incl. shadow+secondary rays, {args.workload}",

@@ -513,6 +513,7 @@ static int drain(rt_scene* s) {
     if (c.overflow) {
       size_t need = 0;
       for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
+      need = std::max<size_t>(need, (size_t)c.seg_need * NSEG);       // the fullest queue segment decides
       s->overflow_need = need;
       // the next frame (blocking retry, or the next async frame) gets larger queues; levels below the truncated
       // one were undercounted, so grow generously
@@ -577,7 +578,7 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
     free_workspace(s);
     s->d_out = keep_out; s->cap_out = keep_cap;
-    size_t q = std::max<size_t>(2 * pixels + 1024, s->min_queue);
+    size_t q = (std::max<size_t>(2 * pixels + 1024, s->min_queue) + NSEG - 1) / NSEG * NSEG;   // NSEG equal segments
     if (q > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
     HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&s->d_hits, q * sizeof(HitRec)));
@@ -1046,6 +1047,7 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   if (c.overflow) {
     size_t need = 0;
     for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
+    need = std::max<size_t>(need, (size_t)c.seg_need * NSEG);
     return fail(RT_ERR_QUEUE_OVERFLOW, "rt_render_static: a level holds >= %zu rays, the static queues hold %zu for a row set of %zu pixels "
                 "(this entry point cannot grow them: use rt_render, or render fewer rows per call)", need, cap, pixels);
   }

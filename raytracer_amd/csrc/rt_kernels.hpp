@@ -50,8 +50,18 @@ struct Counters {
   // index, each with its counter in a cache line of its own: a single device counter sustains only ~88 atomics
   // per microsecond, and a 4K pool frame queues ~1e5 pairs from as many different waves.
   uint32_t fixq[64 * 32];       // count of sub-queue q at fixq[q * 32]
+  // Bounce-ray queues are cut into NSEG segments of queue_cap / NSEG slots, each with its own append counter in a
+  // cache line of its own (same reason): a wave appends its children with ONE atomic to the segment its index
+  // selects, no block-level aggregation or barrier.  segcnt[parity of the level the rays belong to][segment * 32].
+  uint32_t segcnt[2][64 * 32];
+  uint32_t seg_need;            // largest segment fill any level reached (unclamped: what an overflowed frame needs)
+  uint32_t stripes_done;        // k_shade_ls: bit s = stripe s has no chunk left
+  uint32_t stripes[32 * 32];    // k_shade_ls: chunk cursors of the NSTRIPE stripes of a level's hit list (stripe * 32)
 };
 constexpr int FIX_QUEUES = 64;
+constexpr int NSEG = 64;
+static_assert(NSEG == 64, "k_trace scans the segment counters with one wave, one lane per segment");
+constexpr int NSTRIPE = 32;
 
 // Radiance-ray queue of one level, struct-of-arrays so that a wave's loads/stores coalesce.
 struct RayQueue {
@@ -110,7 +120,7 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
 
 // Small hierarchies (<= LDS_NODES nodes, 32 KiB) are staged in LDS too: the walk is a chain of
 // dependent loads, LDS latency is several times shorter than L2's.
-constexpr int LDS_NODES = 988;      // (k_trace's nodes + hit staging + wave lists then fit four workgroups per CU)
+constexpr int LDS_NODES = 980;      // (k_trace's nodes + hit staging + wave lists then fit four workgroups per CU)
 template <bool LDS_SCENE>
 __device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   Accel a = sc.ac;
@@ -220,15 +230,56 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, Fra
   // cones are too wide, and the attempt costs them ~3 %.  RT_DEBUG_STATS=4096: per-lane walks everywhere (A/B).
   const bool wave_mode = !LDS_SCENE && ac.n_nodes > 0 && ac.n_cut > 0;
   const bool try_wave = level == 0 && !(fp.debug & 4096u);
-  uint32_t count = C->n_rays[level];
-  if (count > fp.queue_cap) count = fp.queue_cap;
-  const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
+  // Level 0: slots are the pixels of the row set.  Deeper levels: the ray queue is cut into NSEG segments (see
+  // Counters::segcnt); a chunk is CHUNK consecutive slots of ONE segment, chunk ids run through the segments in order.
+  __shared__ uint32_t s_segfirst[NSEG + 1];     // first chunk id of each segment
+  const uint32_t seg_cap = fp.queue_cap / NSEG;
+  uint32_t n_chunks;
+  if (level == 0) {
+    uint32_t count0 = C->n_rays[0];
+    if (count0 > fp.queue_cap) count0 = fp.queue_cap;
+    n_chunks = (count0 + CHUNK - 1) / CHUNK;
+    if (threadIdx.x == 0) { s_segfirst[0] = 0; s_segfirst[1] = n_chunks; }
+  } else {
+    if (threadIdx.x < 64) {                        // lane q: segment q; inclusive scans over the wave
+      const uint32_t raw = C->segcnt[level & 1][threadIdx.x * 32];
+      const uint32_t nq_ = min(raw, seg_cap);
+      uint32_t ch = (nq_ + CHUNK - 1) / CHUNK, tot = nq_, worst = raw;
+#pragma unroll
+      for (int o_ = 1; o_ < 64; o_ <<= 1) {
+        const uint32_t a = __shfl_up(ch, o_), b = __shfl_up(tot, o_);
+        if ((int)threadIdx.x >= o_) { ch += a; tot += b; }
+        worst = max(worst, (uint32_t)__shfl_xor((int)worst, o_));
+      }
+      s_segfirst[threadIdx.x + 1] = ch;
+      if (threadIdx.x == 0) s_segfirst[0] = 0;
+      if (blockIdx.x == 0 && threadIdx.x == 63) { C->n_rays[level] = tot; atomicMax(&C->seg_need, worst); }
+    }
+    // the segment counters the NEXT level's rays will be appended to (by this level's shade kernel)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < NSEG; i += BLOCK) C->segcnt[(level + 1) & 1][i * 32] = 0u;
+  }
+  // chunk cursors of this level's shade kernel
+  if (blockIdx.x == 0) { if (threadIdx.x < NSTRIPE) C->stripes[threadIdx.x * 32] = 0u; if (threadIdx.x == 0) C->stripes_done = 0u; }
+  __syncthreads();
+  n_chunks = s_segfirst[level == 0 ? 1 : NSEG];
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // chunk -> (first slot, number of rays in it)
+    uint32_t slot0, count;       // slots [slot0, count) of this chunk are rays (count is an END, like the old level size)
+    if (level == 0) {
+      slot0 = chunk * CHUNK;
+      count = C->n_rays[0]; if (count > fp.queue_cap) count = fp.queue_cap;
+    } else {
+      int lo_ = 0, hi_ = NSEG;                     // last segment whose first chunk id is <= chunk
+      while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (s_segfirst[mid] <= chunk) lo_ = mid; else hi_ = mid; }
+      uint32_t nq_ = C->segcnt[level & 1][lo_ * 32]; if (nq_ > seg_cap) nq_ = seg_cap;
+      slot0 = (uint32_t)lo_ * seg_cap + (chunk - s_segfirst[lo_]) * CHUNK;
+      count = (uint32_t)lo_ * seg_cap + nq_;
+    }
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < CHUNK / BLOCK; ++it) {
-      const uint32_t slot = chunk * CHUNK + it * BLOCK + threadIdx.x;
+      const uint32_t slot = slot0 + it * BLOCK + threadIdx.x;
       const bool active = slot < count;
       bool hit = false;
       int k = -1; double t = RT_INF;
@@ -281,29 +332,55 @@ __device__ __forceinline__ bool seq_background_term(const FrameParams& fp, int l
   return fp.sequential && mat[10] != 0.0 && !(level < fp.max_depth && mat[10] > EPS);
 }
 
+// Segment for the children of 64-hit chunk `chunk` of a level with `count` hits: groups of G consecutive chunks
+// share a segment (their children stay together in the queue: neighbouring hits -> neighbouring rays for the next
+// k_trace), the groups are dealt round-robin, and G is chosen so that every segment receives >= 8 groups whenever
+// the level has that many chunks — the segments then fill evenly whatever wave happens to shade which chunk.
+__device__ __forceinline__ uint32_t spawn_segment(uint32_t chunk, uint32_t count) {
+  const uint32_t n_chunks = (count + 63u) >> 6;
+  const uint32_t G = max(1u, n_chunks / (uint32_t)(NSEG * 8));
+  return (chunk / G) & (uint32_t)(NSEG - 1);
+}
+
+// Reserve queue slots for the children of one wave's hits: ONE atomic per wave on the counter of segment `seg`.  Returns physical slots (segment * seg_cap + offset), 0xFFFFFFFF = no slot
+// (not needed, or the segment is full: Counters::overflow is set, the frame is rendered again with larger queues).
+// Must be called convergently by every lane of the wave.
+__device__ __forceinline__ void spawn_reserve(Counters* C, const FrameParams& fp, int level, uint32_t seg, bool needT, bool needR,
+                                              uint32_t* sT, uint32_t* sR) {
+  *sT = *sR = 0xFFFFFFFFu;
+  const unsigned long long mT = __ballot(needT), mR = __ballot(needR);
+  const uint32_t nT = (uint32_t)__popcll(mT), nR = (uint32_t)__popcll(mR);
+  if (nT + nR == 0u) return;
+  seg &= (uint32_t)(NSEG - 1);
+  uint32_t base = 0;
+  if (__lane_id() == 0) base = atomicAdd(&C->segcnt[(level + 1) & 1][seg * 32], nT + nR);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  const uint32_t seg_cap = fp.queue_cap / NSEG;
+  const uint32_t oT = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mT >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mT, 0u));
+  const uint32_t oR = base + nT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
+  if (needT) { if (oT < seg_cap) *sT = seg * seg_cap + oT; else C->overflow = 1u; }
+  if (needR) { if (oR < seg_cap) *sR = seg * seg_cap + oR; else C->overflow = 1u; }
+}
+
 __device__ __forceinline__ void spawn_children(bool active, int level, const FrameParams& fp, const double* mat,
-                                               const RayIn& r, d3 hp, d3 n, RayQueue& nq, Counters* C) {
+                                               const RayIn& r, d3 hp, d3 n, RayQueue& nq, Counters* C, uint32_t seg) {
   bool deeper = active && level < fp.max_depth;
   bool needT = deeper && (mat[10] > EPS);
   bool needR = deeper && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS);
-  uint32_t sT = wave_append(&C->n_rays[level + 1], needT);
-  if (needT) {
-    if (sT < fp.queue_cap) {
-      nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
-      nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
-      nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
-      nq.pix[sT] = r.lp;
-    } else C->overflow = 1u;
+  uint32_t sT, sR;
+  spawn_reserve(C, fp, level, seg, needT, needR, &sT, &sR);
+  if (sT != 0xFFFFFFFFu) {
+    nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
+    nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
+    nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
+    nq.pix[sT] = r.lp;
   }
-  uint32_t sR = wave_append(&C->n_rays[level + 1], needR);
-  if (needR) {
-    if (sR < fp.queue_cap) {
-      double dn = dot3(r.d, n);                                    // reflect_batch, :34-36
-      nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
-      nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
-      nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
-      nq.pix[sR] = r.lp;
-    } else C->overflow = 1u;
+  if (sR != 0xFFFFFFFFu) {
+    double dn = dot3(r.d, n);                                    // reflect_batch, :34-36
+    nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
+    nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
+    nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
+    nq.pix[sR] = r.lp;
   }
 }
 
@@ -386,6 +463,86 @@ __device__ __forceinline__ double soft_shadow_exact(const DevScene& sc, const Pr
     T = total / (double)(n_sh * n_sh);                                           // :243
   }
   return T;
+}
+
+// The shadow ray of grid cell `cell` of light li from the shadow origin p, formed exactly as the reference forms it
+// (ray_tracer.py:184-235, fp64, pixel-keyed jitter): origin p + dir*1e-6, unit direction, length |S - p| - 1e-6.
+struct ExactRay { d3 so, dir; double maxdist; };
+__device__ __forceinline__ ExactRay exact_shadow_ray(const DevScene& sc, d3 p, int li, int n_sh, uint32_t seed, uint32_t gpix,
+                                                     uint32_t depth, int cell) {
+  const double* lg = sc.lights + LIGHT_STRIDE * li;
+  const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+  d3 sp = Lp;
+  if (n_sh > 1) {
+    const d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);                       // :198-200
+    const double ldist = norm3(tl);
+    const d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+    const d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);            // :202-205
+    d3 right = cross3(ld, ref);                                                  // :207-209
+    double rn = norm3(right); if (rn < EPS) rn = EPS;
+    right = mk3(right.x / rn, right.y / rn, right.z / rn);
+    d3 up = cross3(right, ld);                                                   // :211-213
+    double un = norm3(up); if (un < EPS) un = EPS;
+    up = mk3(up.x / un, up.y / un, up.z / un);
+    const double radius = lg[8], cw = radius / n_sh;                             // :215
+    const JitKey key = jit_light_key(seed, gpix, depth, (uint32_t)li);
+    const int i = cell / n_sh, j = cell - i * n_sh;
+    const double oi = -radius / 2 + cw * (i + (double)jit_ui(key, (uint32_t)cell));
+    const double oj = -radius / 2 + cw * (j + (double)jit_uj(key, (uint32_t)cell));
+    sp = mk3((Lp.x + oi * right.x) + oj * up.x, (Lp.y + oi * right.y) + oj * up.y, (Lp.z + oi * right.z) + oj * up.z);
+  }
+  const d3 ts = mk3(sp.x - p.x, sp.y - p.y, sp.z - p.z);
+  const double dist = norm3(ts);
+  ExactRay r;
+  r.dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
+  r.so = mk3(p.x + r.dir.x * EPS, p.y + r.dir.y * EPS, p.z + r.dir.z * EPS);
+  r.maxdist = dist - EPS;
+  return r;
+}
+
+// The switch of the light basis' helper vector, |ld.x| >= 0.9, decided as the reference decides it (fp64,
+// ray_tracer.py:198-205): the fp32 kernels call this when their own |ld.x| is within rounding of 0.9.
+__device__ __forceinline__ bool basis_switch_exact(const DevScene& sc, d3 p, int li) {
+  const double* lg = sc.lights + LIGHT_STRIDE * li;
+  const d3 tl = mk3(lg[0] - p.x, lg[1] - p.y, lg[2] - p.z);
+  return fabs(tl.x / norm3(tl)) >= 0.9;
+}
+
+// The crossings of ONE primitive by a shadow ray, each decided in fp64 with the arithmetic of the reference's
+// intersect_batch (sphere.py:49-71, infinite_plane.py:30-42, cube.py:76-120): in1 / in2 = the first / second crossing
+// lies in (1e-6, maxdist) — the crossings the reference's walk (ray_tracer.py:257-291) multiplies transparencies for.
+__device__ __forceinline__ void exact_crossings(const Prim& pr, d3 o, d3 d, double maxdist, bool* in1, bool* in2) {
+  *in1 = *in2 = false;
+  if (pr.type == 0) {
+    const d3 oc = mk3(o.x - pr.a[0], o.y - pr.a[1], o.z - pr.a[2]);
+    const double a = dot3(d, d), b = 2.0 * dot3(oc, d), c = dot3(oc, oc) - pr.a[4];
+    const double disc = b * b - (4 * a) * c;
+    if (!(disc >= 0)) return;
+    const double sq = sqrt(disc);
+    const double t1 = (-b - sq) / (2 * a), t2 = (-b + sq) / (2 * a);
+    *in1 = (t1 > HIT_EPS) & (t1 < maxdist);
+    *in2 = (t2 > HIT_EPS) & (t2 < maxdist);
+  } else if (pr.type == 1) {
+    const double t = plane_t(pr, o, d);
+    *in1 = t < maxdist;
+  } else {
+    double tmin = -RT_INF, tmax = RT_INF;
+    bool valid = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const double dv = comp(d, ax), ov = comp(o, ax);
+      const bool parallel = fabs(dv) < PAR_EPS;
+      if (parallel && ((ov < pr.a[ax]) || (ov > pr.a[3 + ax]))) valid = false;
+      if (!parallel && valid) {
+        const double t1 = (pr.a[ax] - ov) / dv, t2 = (pr.a[3 + ax] - ov) / dv;
+        tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
+        valid = valid && (tmin <= tmax);
+      }
+    }
+    if (!valid) return;
+    *in1 = (tmin >= HIT_EPS) & (tmin < maxdist);
+    *in2 = (tmax >= HIT_EPS) & (tmax < maxdist);
+  }
 }
 
 struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading result of one hit
@@ -478,7 +635,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
       fb_put(fb, level == 0, r.lp, r.w.x * e.c[0], r.w.y * e.c[1], r.w.z * e.c[2]);      // :563
       atomicAdd(&C->queries, (unsigned long long)queries);
     }
-    spawn_children(active, level, fp, mat, r, hp, n, nq, C);
+    spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
   }
 }
 
@@ -496,24 +653,49 @@ __global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp
   const uint32_t qi = blockIdx.x % FIX_QUEUES, slice = blockIdx.x / FIX_QUEUES, n_slices = gridDim.x / FIX_QUEUES;
   uint32_t count = C->fixq[qi * 32];
   if (count > fp.fix_cap) count = fp.fix_cap;
-  if (slice * BLOCK >= count) return;           // (uniform over the block; most blocks of most frames)
+  // A record's n x n shadow walks are independent: they go to the lanes of a GROUP of g lanes (g = the power of two
+  // >= n^2, at most 64), 64 / g records per wave — a record's latency is one walk, not n^2 of them.
+  const int n_cells = fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1;
+  int g = 1; while (g < n_cells && g < 64) g <<= 1;
+  const uint32_t per_block = (uint32_t)(BLOCK / g);
+  if (slice * per_block >= count) return;       // (uniform over the block; most blocks of most frames)
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   const FixRec* __restrict__ mine = fix + (size_t)qi * fp.fix_cap;
-  for (uint32_t base = slice * BLOCK; base < count; base += n_slices * BLOCK) {
-    const uint32_t i = base + threadIdx.x;
-    {
-      // the idle lanes of a sub-queue's last wave re-test a copy of its last record (result dropped): the
-      // conservative pre-pass of soft_shadow_exact (fan_cull) is wave-level
-      const bool live = i < count;
-      const FixRec rec = mine[live ? i : count - 1];
-      JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = rec.gpix; jit.depth = rec.level;
-      int queries = 0;
-      const double T = soft_shadow_exact(sc, P, mk3(rec.px, rec.py, rec.pz), (int)rec.light, fp.n_shadow, jit, &queries,
-                                         false, fp.plane_thr, &ac);
+  const uint32_t member = threadIdx.x & (uint32_t)(g - 1);
+  for (uint32_t base = slice * per_block; base < count; base += n_slices * per_block) {
+    const uint32_t i = base + threadIdx.x / (uint32_t)g;
+    // the idle groups of a sub-queue's last wave re-test a copy of its last record (result dropped): the
+    // conservative pre-pass (fan_cull) is wave-level
+    const bool live = i < count;
+    const FixRec rec = mine[live ? i : count - 1];
+    const d3 p = mk3(rec.px, rec.py, rec.pz);
+    const int li = (int)rec.light;
+    const double* lg = sc.lights + LIGHT_STRIDE * li;
+    // small scenes: conservative candidate set + fully-lit / umbra claim (rt_device.hpp, fan_cull); the lanes of a wave
+    // may hold different records: the candidate set is the union, the claims are per lane
+    PrimMask cmask = PrimMask::all();
+    bool claim = false; double claimed = 0.0;
+    if (LDS_SCENE) {
+      const FanCull fc = fan_cull(sc, P, p, mk3(lg[0], lg[1], lg[2]), fp.n_shadow > 1 ? 0.7072f * (float)lg[8] : 0.0f);
+      cmask = fc.act;
+      if (!fc.lane_can) { claim = true; claimed = 1.0; }
+      else if (fc.lane_full) { claim = true; claimed = 0.0; }
+    }
+    double tsum = 0.0;
+    if (!__all(claim)) {
+      for (int cell = (int)member; cell < n_cells; cell += g) {
+        const ExactRay er = exact_shadow_ray(sc, p, li, fp.n_shadow, fp.seed, rec.gpix, rec.level, cell);
+        int queries = 0;
+        tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &queries, false, fp.plane_thr, &ac, cmask);
+      }
+      for (int o_ = g >> 1; o_ > 0; o_ >>= 1) tsum += __shfl_xor(tsum, o_);
+    }
+    const double T = claim ? claimed : tsum / (double)n_cells;
+    const float Tf = (float)T;
+    if (live && member == 0u && Tf != 0.0f) {
       float* dst = fb + 3 * (size_t)rec.lp;
-      const float Tf = (float)T;
-      if (live && Tf != 0.0f) { atomicAdd(dst + 0, rec.m[0] * Tf); atomicAdd(dst + 1, rec.m[1] * Tf); atomicAdd(dst + 2, rec.m[2] * Tf); }
+      atomicAdd(dst + 0, rec.m[0] * Tf); atomicAdd(dst + 1, rec.m[1] * Tf); atomicAdd(dst + 2, rec.m[2] * Tf);
     }
   }
 }

@@ -119,7 +119,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
         // light-facing basis (ray_tracer.py:198-213)
         const f3 ld = scalef(tl, raw_rsq(dotf(tl, tl)));
-        const f3 ref = (fabsf(ld.x) >= 0.9f) ? mkf(0, 1, 0) : mkf(1, 0, 0);
+        bool sw = fabsf(ld.x) >= 0.9f;
+        if (__any(fabsf(fabsf(ld.x) - 0.9f) < 1e-5f)) {                      // within rounding of the switch: decide it in fp64
+          if (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f) sw = basis_switch_exact(sc, p, li);
+        }
+        const f3 ref = sw ? mkf(0, 1, 0) : mkf(1, 0, 0);
         const f3 right = normalize_clamped(crossf(ld, ref));
         const f3 up = normalize_clamped(crossf(right, ld));
         const float radius = (float)lg[8];
@@ -135,8 +139,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         constexpr float U8 = 12.0f * 6.0e-8f;
         const float RLx = n_sh > 1 ? 0.7072f * radius * 1.001f : 0.0f;
         const float T0x = dotf(tl, tl);
-        // the light within 3 sample-square radii of the hit, or the 0.9 switch of the basis within rounding
-        if ((T0x < 9.0f * RLx * RLx) | (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f) | !(T0x > 1e-12f)) unc = 1.0f;
+        // the light within 3 sample-square radii of the hit
+        if ((T0x < 9.0f * RLx * RLx) | !(T0x > 1e-12f)) unc = 1.0f;
         // reach of the sample square + the error of a shadow segment's far end (grows with the segment's length)
         const float reach = RLx + 1e-5f * (1.0f + fabsf((float)lg[0]) + fabsf((float)lg[1]) + fabsf((float)lg[2])) + 2.0f * U8 * raw_sqrt(T0x);
         // LDS-staged scenes (<= 128 records): conservative candidate set of this (wave, light) and the
@@ -240,6 +244,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             tr[s] = (cellidx < n_cells) ? 1.0f : 0.0f;
             if (KEEP_INV) { ix[s] = raw_rcp(dx[s]); iy[s] = raw_rcp(dy[s]); iz[s] = raw_rcp(dz[s]); }
           }
+          // one primitive's crossings folded into a sample's transmission product
+          auto apply = [&](float& t_, bool in1, bool in2, float tau) __attribute__((always_inline)) {
+            if (OPAQUE) { t_ = (in1 | in2) ? 0.0f : t_; }
+            else { t_ *= in1 ? tau : 1.0f; t_ *= in2 ? tau : 1.0f; }
+          };
+          // Samples whose decision for primitive s_ lay within the fp32 error bound were left out above: decide them in
+          // fp64 from the exact shadow ray, here and now (rare: ~1e-5 of the tests; the wave pays the fp64 code only when
+          // one of its lanes has such a sample).  (CH <= 25 samples: one bit each.)
+          auto retest = [&](const Prim& s_, uint32_t fmask, float tau) __attribute__((always_inline)) {
+            while (__any(fmask != 0u)) {                      // (far hits: usually every sample of the chunk, one per turn)
+              bool e1 = false, e2 = false;
+              const int s_star = fmask ? __ffs((int)fmask) - 1 : -1;
+              if (fmask) {
+                const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, c * CH + s_star);
+                exact_crossings(s_, er.so, er.dir, er.maxdist, &e1, &e2);
+              }
+#pragma unroll
+              for (int s = 0; s < CH; ++s)
+                if (s == s_star) apply(tr[s], e1, e2, tau);
+              fmask &= fmask - 1u;
+            }
+          };
           // per-primitive blocks: everything that depends on (hit, primitive) once, then CH samples
           auto do_sphere = [&](const Prim& s_) __attribute__((always_inline)) {   // sphere.py:49-71
             const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
@@ -258,11 +284,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             // a root can only come near the 2e-6 bound when p lies within ~1e-5 of the sphere's surface
             // (t1 t2 = cc): the hit's own sphere, or one touching it at the hit point
             const bool nearsurf = fabsf(cc) <= 1.2e-5f * (ocn + r_);
+            uint32_t fmask = 0u;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float b = fmaf(oc.z, dz[s], fmaf(oc.y, dy[s], oc.x * dx[s]));   // oc.d  (a = d.d = 1)
               const float disc = fmaf(b, b, -cc);
-              unc = fmaxf(unc, fmaf(kap, fabsf(b), kap0) - fabsf(disc));   // the ray grazes the silhouette within rounding
+              bool f = fmaf(kap, fabsf(b), kap0) >= fabsf(disc);        // the ray grazes the silhouette within rounding
               const float sq = raw_sqrt(disc);                          // NaN on a miss: both tests fail
               // roots {q, cc/q} with q the root that does not cancel: the other one can be the crossing of
               // the hit's own sphere at t' ~ 1e-6/cos, which has to be compared with the 2e-6 bound
@@ -270,16 +297,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const float t2 = cc * raw_rcp(t1);
               const bool in1 = (t1 > T_LO) & (t1 < md[s]);
               const bool in2 = (t2 > T_LO) & (t2 < md[s]);
-              if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
-              else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
               if (nearsurf) {
                 // a root within 1e-3 (relative) of the 2e-6 bound is not decided in fp32 — unless the other root blocks
                 // an opaque scene's sample anyway
                 const bool n1 = fabsf(t1 - T_LO) <= 1e-3f * T_LO, n2 = fabsf(t2 - T_LO) <= 1e-3f * T_LO;
                 const bool open_ = OPAQUE ? !((in1 & !n1) | (in2 & !n2)) : true;
-                if ((n1 | n2) & open_) unc = 1.0f;
+                f |= (n1 | n2) & open_;
               }
+              f &= (c * CH + s) < n_cells;
+              if (!f) apply(tr[s], in1, in2, tau);
+              fmask |= f ? (1u << s) : 0u;
             }
+            retest(s_, fmask, tau);
           };
           auto do_box = [&](const Prim& s_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
             const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
@@ -294,6 +323,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             // p within ~1e-5 of one of the box's face planes: slab roots can come near the 2e-6 bound
             const float fmin_ = fminf(fminf(fminf(fabsf(lo.x), fabsf(hi.x)), fminf(fabsf(lo.y), fabsf(hi.y))), fminf(fabsf(lo.z), fabsf(hi.z)));
             const bool nearsurf = fmin_ <= 1.2e-5f;
+            uint32_t fmask = 0u;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float jx = KEEP_INV ? ix[KEEP_INV ? s : 0] : raw_rcp(dx[s]), jy = KEEP_INV ? iy[KEEP_INV ? s : 0] : raw_rcp(dy[s]),
@@ -306,19 +336,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const bool ok = tn <= tf;
               const bool in1 = ok & (tn > T_LO) & (tn < md[s]);
               const bool in2 = ok & (tf > T_LO) & (tf < md[s]);
-              if (OPAQUE) { tr[s] = (in1 | in2) ? 0.0f : tr[s]; }
-              else { tr[s] *= in1 ? tau : 1.0f; tr[s] *= in2 ? tau : 1.0f; }
               // the ray passes an edge of the box within the slabs' rounding: each slab value carries the relative error
-              // of 1/d (8 ulp of a unit vector's component) plus a few ulp; a component within 1e-3 of parallel is never decided
+              // of 1/d (12 ulp of a unit vector's component) plus a few ulp; a component within 1e-3 of parallel is never decided
               const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
               const float rel = fmaf(U8, jm, 4.0f * 6.0e-8f);
-              if ((fabsf(tf - tn) <= 2.0f * rel * (fabsf(tn) + fabsf(tf))) | (jm > 1e3f)) unc = 1.0f;
+              bool f = (fabsf(tf - tn) <= 2.0f * rel * (fabsf(tn) + fabsf(tf))) | (jm > 1e3f);
               if (nearsurf) {
                 const bool n1 = fabsf(tn - T_LO) <= 1e-3f * T_LO, n2 = fabsf(tf - T_LO) <= 1e-3f * T_LO;
                 const bool open_ = OPAQUE ? !((in1 & !n1) | (in2 & !n2)) : true;
-                if (ok & (n1 | n2) & open_) unc = 1.0f;
+                f |= ok & (n1 | n2) & open_;
               }
+              f &= (c * CH + s) < n_cells;
+              if (!f) apply(tr[s], in1, in2, tau);
+              fmask |= f ? (1u << s) : 0u;
             }
+            retest(s_, fmask, tau);
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
             if (!cand.has(k)) continue;
@@ -329,16 +361,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             // a sample of the light may lie on the plane (crossing at the far end of the segment)
             if (fabsf(fmaf(N.z, tl.z, fmaf(N.y, tl.y, N.x * tl.x)) - num) <= reach + 1e-5f * fabsf(num)) unc = 1.0f;
             const bool nearsurf = fabsf(num) <= 1.2e-5f;                 // p on the plane: the hit's own plane
+            uint32_t fmask = 0u;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float den = fmaf(N.z, dz[s], fmaf(N.y, dy[s], N.x * dx[s]));
               const float t1 = num * raw_rcp(den);
               const bool in1 = (t1 > T_LO) & (t1 < md[s]);               // den == 0 -> inf/NaN -> no hit
-              if (OPAQUE) { tr[s] = in1 ? 0.0f : tr[s]; }
-              else tr[s] *= in1 ? tau : 1.0f;
-              unc = fmaxf(unc, 2.0f * U8 - fabsf(den));                   // ray parallel to the plane within rounding
-              if (nearsurf & (fabsf(t1 - T_LO) <= 1e-3f * T_LO)) unc = 1.0f;
+              // ray parallel to the plane within rounding; own plane: the root within 1e-3 of the 2e-6 bound
+              bool f = (fabsf(den) <= 2.0f * U8) | (nearsurf & (fabsf(t1 - T_LO) <= 1e-3f * T_LO));
+              f &= (c * CH + s) < n_cells;
+              if (!f) apply(tr[s], in1, false, tau);
+              fmask |= f ? (1u << s) : 0u;
             }
+            retest(s_, fmask, tau);
           }
           if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {
             // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
@@ -594,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         fb_put(fb, level == 0, r.lp, (float)r.w.x * ((dif[0] + spc[0]) * one_m + bt[0]),
                (float)r.w.y * ((dif[1] + spc[1]) * one_m + bt[1]), (float)r.w.z * ((dif[2] + spc[2]) * one_m + bt[2]));
     }
-    spawn_children(active, level, fp, mat, r, hp, n, nq, C);
+    spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
   }
 }
 

@@ -336,12 +336,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // exact fp64 geometry of each lane's hit, parked for the spawn step and the re-test queue (hit point, normal, ray
   // direction, weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
   __shared__ double s_geo[12][BLOCK];
-  __shared__ uint32_t s_wcnt[BLOCK / 64][2];
-  __shared__ uint32_t s_base;
   const int n_sh = fp.n_shadow;
   const int n_side = n_sh > 1 ? n_sh : 1;
   const int n_cells = n_side * n_side;
   const bool brute = fp.brute != 0u;
+  if (C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
   {
     const int words = sc.n * (int)(sizeof(Prim) / 16);
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
@@ -410,29 +409,56 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
   uint32_t count = C->n_hits[level];
   if (count > fp.queue_cap) count = fp.queue_cap;
-  const uint32_t n_iters = (count + BLOCK - 1) / BLOCK;
   const float inv_cells = 1.0f / (float)n_cells;
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
   const uint32_t all_prims = ((1u << nS) - 1u) | (((1u << nP) - 1u) << 16);
 
-  // Blocks take 256-hit chunks from a device counter (Counters::work_shade, zeroed per frame): chunk costs
-  // differ by several x (penumbra vs fully lit), and with a fraction of a frame per GPU there are only a
-  // few chunks per resident block, so a static round-robin leaves a long tail.
-  __shared__ uint32_t s_iter;
+  // Waves work independently (no block barrier after the staging above): each takes 64-hit chunks — at level 0 an
+  // 8x8 pixel tile — until the level's hit list is used up.  Chunk costs differ by several x (penumbra vs fully
+  // lit), so chunks are handed out dynamically; a single device counter sustains only ~88 atomics per microsecond
+  // (a 4K frame's level 0 has 130k chunks), so the list is cut into NSTRIPE stripes with a cursor each: a wave works
+  // through its home stripe, then moves to the stripe with the most chunks left.
+  const uint32_t n_chunks = (count + 63u) / 64u;
+  const uint32_t cps = (n_chunks + NSTRIPE - 1) / NSTRIPE;         // chunks per stripe
+  uint32_t stripe = (blockIdx.x * (BLOCK / 64) + wave) % NSTRIPE;
   // RT_DEBUG_STATS bit 1 << 20 (audit build): wave cycles per phase -> Counters::dbg (hit setup, light setup, sample loops, all)
   const bool prof = (RT_DBG(fp) & (1u << 20)) != 0u;
   long long ck_hit = 0, ck_setup = 0, ck_loop = 0, ck_sync = 0;
   const long long ck_begin = prof ? clock64() : 0;
-  for (;;) {
-    const long long ck_s0 = prof ? clock64() : 0;
-    if (threadIdx.x == 0) s_iter = atomicAdd(&C->work_shade[level], 1u);
-    __syncthreads();
-    const uint32_t iter = s_iter;
-    __syncthreads();                       // everyone has read s_iter before thread 0 overwrites it
-    if (prof) ck_sync += clock64() - ck_s0;
-    if (iter >= n_iters) break;
-    const uint32_t h = iter * BLOCK + threadIdx.x;
+  // A global atomic with return takes ~1 us and a chunk only ~6: the cursor of the NEXT chunk is fetched while the
+  // current one is shaded (issued after the chunk's global loads, consumed at its end), and so is the queue slot
+  // reservation of the chunk's children.
+  auto steal = [&](uint32_t i_) -> uint32_t {      // chunk for cursor value i_ of `stripe`; when that stripe is used up: go to the fullest one
+    for (;;) {
+      if (i_ < cps && stripe * cps + i_ < n_chunks) return stripe * cps + i_;
+      // lane s looks at stripe s (device-scope load: not from this CU's vector cache); the wave moves to the stripe
+      // with the most chunks left — one load and one atomic per move, one load to learn that the level is finished
+      int left = 0;
+      if (lane < (uint32_t)NSTRIPE) {
+        const uint32_t cur = __hip_atomic_load(&C->stripes[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t first = lane * cps;
+        const uint32_t n_s = first < n_chunks ? min(cps, n_chunks - first) : 0u;
+        left = cur < n_s ? (int)(n_s - cur) : 0;
+      }
+      int key = (left << 6) | (int)(63u - lane);     // most chunks left, lowest stripe on ties
+#pragma unroll
+      for (int o_ = 32; o_ > 0; o_ >>= 1) key = max(key, __shfl_xor(key, o_));
+      if ((key >> 6) <= 0) return 0xFFFFFFFFu;
+      stripe = 63u - (uint32_t)(key & 63);
+      uint32_t j_ = 0;
+      if (lane == 0) j_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+      i_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)j_);
+    }
+  };
+  uint32_t chunk;
+  {
+    uint32_t j_ = 0;
+    if (lane == 0) j_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+    chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)j_));
+  }
+  while (chunk != 0xFFFFFFFFu) {
+    const uint32_t h = chunk * 64u + lane;
     const bool active = h < count;
     long long ck_t = prof ? clock64() : 0;
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
@@ -471,6 +497,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         s_geo[9][t_] = r.w.x; s_geo[10][t_] = r.w.y; s_geo[11][t_] = r.w.z;
       }
     }
+    // (all global loads of this chunk are done) fetch the next chunk's cursor and reserve the children's queue slots
+    uint32_t next_cursor = 0;
+    if (lane == 0) next_cursor = atomicAdd(&C->stripes[stripe * 32], 1u);
+    const double* mat_early = s_matd[mat_idx];
+    const bool needT = spawn_level && active && (mat_early[10] > EPS);
+    const bool needR = spawn_level && active && (mat_early[6] > EPS || mat_early[7] > EPS || mat_early[8] > EPS);
+    const unsigned long long mT = __ballot(needT), mR = __ballot(needR);
+    const uint32_t nT = (uint32_t)__popcll(mT), nR = (uint32_t)__popcll(mR);
+    const uint32_t seg = spawn_segment(chunk, count);
+    uint32_t spawn_base = 0;
+    if (lane == 0 && nT + nR != 0u) spawn_base = atomicAdd(&C->segcnt[(level + 1) & 1][seg * 32], nT + nR);
     bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
     uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
     float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
@@ -576,7 +613,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
-      const f3 ref = (fabsf(ld.x) >= 0.9f) ? mkf(0, 1, 0) : mkf(1, 0, 0);
+      bool sw = fabsf(ld.x) >= 0.9f;
+      if (__any(active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))) {             // within rounding of the switch: decide it in fp64
+        const uint32_t t_ = threadIdx.x;
+        if (active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))
+          sw = basis_switch_exact(sc, mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS), li);
+      }
+      const f3 ref = sw ? mkf(0, 1, 0) : mkf(1, 0, 0);
       const f3 right = normalize_clamped(crossf(ld, ref));
       const f3 up = normalize_clamped(crossf(right, ld));
       const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
@@ -719,10 +762,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                       T0, T1, T2, tol.kap, fl);
         // also undecided in fp32: the light within 3 sample-square radii of the hit (|ts| is then not comparable
-        // to |tl|, which the bounds assume), the 0.9 switch of the basis (ray_tracer.py:202-205) within rounding
+        // to |tl|, which the bounds assume)
         // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
         const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
-        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f) | !(T0 > 1e-12f) | far;
+        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far;
       }
       if (prof) { const long long t = clock64(); ck_loop += t - ck_t; ck_t = t; }
       if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
@@ -779,49 +822,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       else { atomicAdd(dst + 0, c0); atomicAdd(dst + 1, c1); atomicAdd(dst + 2, c2); }
     }
     const long long ck_s1 = prof ? clock64() : 0;
-    if (spawn_level) {                                                     // ray_tracer.py:565-595
-      const bool needT = active && (mat[10] > EPS);
-      const bool needR = active && (mat[6] > EPS || mat[7] > EPS || mat[8] > EPS);
-      const unsigned long long mT = __ballot(needT), mR = __ballot(needR);
-      if (lane == 0) { s_wcnt[wave][0] = (uint32_t)__popcll(mT); s_wcnt[wave][1] = (uint32_t)__popcll(mR); }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) tot += s_wcnt[w][0] + s_wcnt[w][1];
-        s_base = tot ? atomicAdd(&C->n_rays[level + 1], tot) : 0u;
-      }
-      __syncthreads();
-      uint32_t base = s_base;
-      for (uint32_t w = 0; w < wave; ++w) base += s_wcnt[w][0] + s_wcnt[w][1];
-      const uint32_t preT = __builtin_amdgcn_mbcnt_hi((uint32_t)(mT >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mT, 0u));
-      const uint32_t preR = __builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
-      const uint32_t sT = base + preT, sR = base + (uint32_t)__popcll(mT) + preR;
+    if (nT + nR != 0u) {                                                   // ray_tracer.py:565-595
+      const uint32_t base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)spawn_base);
+      const uint32_t seg_cap = fp.queue_cap / NSEG;
+      const uint32_t oT = base_ + __builtin_amdgcn_mbcnt_hi((uint32_t)(mT >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mT, 0u));
+      const uint32_t oR = base_ + nT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
+      uint32_t sT = 0xFFFFFFFFu, sR = 0xFFFFFFFFu;
+      if (needT) { if (oT < seg_cap) sT = seg * seg_cap + oT; else C->overflow = 1u; }
+      if (needR) { if (oR < seg_cap) sR = seg * seg_cap + oR; else C->overflow = 1u; }
       if (needT || needR) {
         const uint32_t t_ = threadIdx.x;
         const d3 hp = mk3(s_geo[0][t_], s_geo[1][t_], s_geo[2][t_]);
         const d3 n = mk3(s_geo[3][t_], s_geo[4][t_], s_geo[5][t_]);
         RayIn r; r.d = mk3(s_geo[6][t_], s_geo[7][t_], s_geo[8][t_]); r.w = mk3(s_geo[9][t_], s_geo[10][t_], s_geo[11][t_]);
         r.lp = lp;
-        if (needT) {
-          if (sT < fp.queue_cap) {
-            nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
-            nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
-            nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
-            nq.pix[sT] = r.lp;
-          } else C->overflow = 1u;
+        if (sT != 0xFFFFFFFFu) {
+          nq.ox[sT] = hp.x - n.x * EPS; nq.oy[sT] = hp.y - n.y * EPS; nq.oz[sT] = hp.z - n.z * EPS;
+          nq.dx[sT] = r.d.x; nq.dy[sT] = r.d.y; nq.dz[sT] = r.d.z;
+          nq.wx[sT] = r.w.x * mat[10]; nq.wy[sT] = r.w.y * mat[10]; nq.wz[sT] = r.w.z * mat[10];
+          nq.pix[sT] = r.lp;
         }
-        if (needR) {
-          if (sR < fp.queue_cap) {
-            const double dn = dot3(r.d, n);                                // reflect_batch, :34-36
-            nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
-            nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
-            nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
-            nq.pix[sR] = r.lp;
-          } else C->overflow = 1u;
+        if (sR != 0xFFFFFFFFu) {
+          const double dn = dot3(r.d, n);                                // reflect_batch, :34-36
+          nq.dx[sR] = r.d.x - (2 * dn) * n.x; nq.dy[sR] = r.d.y - (2 * dn) * n.y; nq.dz[sR] = r.d.z - (2 * dn) * n.z;
+          nq.ox[sR] = hp.x + n.x * EPS; nq.oy[sR] = hp.y + n.y * EPS; nq.oz[sR] = hp.z + n.z * EPS;
+          nq.wx[sR] = r.w.x * mat[6]; nq.wy[sR] = r.w.y * mat[7]; nq.wz[sR] = r.w.z * mat[8];
+          nq.pix[sR] = r.lp;
         }
       }
-      __syncthreads();   // s_wcnt / s_base are reused by the next iteration
     }
+    chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)next_cursor));
     if (prof) ck_sync += clock64() - ck_s1;
   }
   if (prof && lane == 0) {
