@@ -511,6 +511,8 @@ __device__ __forceinline__ bool basis_switch_exact(const DevScene& sc, d3 p, int
 // The crossings of ONE primitive by a shadow ray, each decided in fp64 with the arithmetic of the reference's
 // intersect_batch (sphere.py:49-71, infinite_plane.py:30-42, cube.py:76-120): in1 / in2 = the first / second crossing
 // lies in (1e-6, maxdist) — the crossings the reference's walk (ray_tracer.py:257-291) multiplies transparencies for.
+// The walk restarts 1e-6 behind every crossing and accepts hits beyond another 1e-6 (:287-288, sphere.py:70-71), so a
+// second crossing of the same primitive closer than 2e-6 to the first (a ray through the very edge of a box) is not seen.
 __device__ __forceinline__ void exact_crossings(const Prim& pr, d3 o, d3 d, double maxdist, bool* in1, bool* in2) {
   *in1 = *in2 = false;
   if (pr.type == 0) {
@@ -521,7 +523,7 @@ __device__ __forceinline__ void exact_crossings(const Prim& pr, d3 o, d3 d, doub
     const double sq = sqrt(disc);
     const double t1 = (-b - sq) / (2 * a), t2 = (-b + sq) / (2 * a);
     *in1 = (t1 > HIT_EPS) & (t1 < maxdist);
-    *in2 = (t2 > HIT_EPS) & (t2 < maxdist);
+    *in2 = (t2 > HIT_EPS) & (t2 < maxdist) & !(*in1 & !(t2 - (t1 + EPS) > HIT_EPS));
   } else if (pr.type == 1) {
     const double t = plane_t(pr, o, d);
     *in1 = t < maxdist;
@@ -541,7 +543,7 @@ __device__ __forceinline__ void exact_crossings(const Prim& pr, d3 o, d3 d, doub
     }
     if (!valid) return;
     *in1 = (tmin >= HIT_EPS) & (tmin < maxdist);
-    *in2 = (tmax >= HIT_EPS) & (tmax < maxdist);
+    *in2 = (tmax >= HIT_EPS) & (tmax < maxdist) & !(*in1 & !(tmax - (tmin + EPS) >= HIT_EPS));
   }
 }
 

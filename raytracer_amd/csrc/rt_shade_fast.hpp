@@ -340,7 +340,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               // of 1/d (12 ulp of a unit vector's component) plus a few ulp; a component within 1e-3 of parallel is never decided
               const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
               const float rel = fmaf(U8, jm, 4.0f * 6.0e-8f);
-              bool f = (fabsf(tf - tn) <= 2.0f * rel * (fabsf(tn) + fabsf(tf))) | (jm > 1e3f);
+              // (or through it on a chord shorter than 2e-6, which the reference's walk sees as ONE crossing)
+              bool f = (fabsf(tf - tn) <= 2.0f * rel * (fabsf(tn) + fabsf(tf)) + 4e-6f) | (jm > 1e3f);
               if (nearsurf) {
                 const bool n1 = fabsf(tn - T_LO) <= 1e-3f * T_LO, n2 = fabsf(tf - T_LO) <= 1e-3f * T_LO;
                 const bool open_ = OPAQUE ? !((in1 & !n1) | (in2 & !n2)) : true;
