@@ -336,6 +336,21 @@ def main():
             roofline["traffic"] = None      # the PMC pass (profiles/) measured full-frame launches on one GPU
         if verify is not None:
             out["verify"] = verify
+        if world == 1:
+            # The drop-in boundary: render_hip(...) as the reference's CLI would call it — scene objects in, host image out
+            # (PCIe-inclusive, so never `value`).  fp32 frames come back as float32 (pinned, pooled); second call onwards.
+            from raytracer_amd.render import render_hip
+            out_dt = np.float32 if precision == "fp32" else np.float64
+            bt = []
+            for _ in range(4):
+                tb = time.perf_counter()
+                himg = render_hip(cam, st, mats, surfs, lights, W, H, precision=precision, jitter=("pixel", 1234), verbose=False, out_dtype=out_dt)
+                bt.append((time.perf_counter() - tb) * 1e3)
+                del himg
+            out["boundary_ms"] = round(min(bt[1:]), 4)
+            out["boundary"] = {"call": f"render_hip(camera, scene_settings, materials, surfaces, lights, {W}, {H}, precision='{precision}', out_dtype={np.dtype(out_dt).name})",
+                               "ms": [round(x, 3) for x in bt], "bytes_to_host": int(W * H * 3 * np.dtype(out_dt).itemsize),
+                               "note": "wall time of the Python call: pack + cached device scene + frame rendered in 4 row bands, each copied to pinned host memory while the next renders"}
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(args.workload, gs, cam, st, mats, surfs, lights, W, H, precision)
             out["cpu_baseline"] = base

@@ -14,6 +14,7 @@
 #ifndef RT_HIP_H
 #define RT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -158,6 +159,12 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, v
 #define RT_STATIC_SCRATCH_MIB 32
 #define RT_STATIC_MAX_PIXELS 131072
 int rt_render_static(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, void* out_device, rt_stats* stats);
+
+/* Pinned (page-locked) host memory for output frames.  rt_render copies a host-output frame band by band while the
+ * next band renders; into pinned memory those copies run asynchronously at PCIe speed.  No counterpart in the
+ * reference, whose image is a NumPy array (ray_tracer.py:599): raytracer_amd.render wraps these buffers as arrays. */
+int rt_host_alloc(size_t bytes, void** out);
+void rt_host_free(void* p);
 
 /* Test/utility exports (host pointers, fp64), one per reference helper:
  * rt_nearest_hit          == find_nearest_intersection_batch (ray_tracer.py:112-127)

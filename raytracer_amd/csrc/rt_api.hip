@@ -240,6 +240,7 @@ struct rt_scene {
   size_t overflow_need = 0;      // largest level size seen by the last overflowed frame
   FixRec* d_fix = nullptr; size_t cap_fix = 0, min_fix = 0;   // re-test queue of the fp32 mode
   int sticky_overflow = 0;       // an RT_FLAG_ASYNC frame overflowed since the last rt_sync / blocking rt_render
+  hipStream_t copy_stream = nullptr;   // host-output frames: device -> host copies of finished row bands (render_banded)
   void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
   void* d_out = nullptr;         // conversion / staging target
   HitRec* d_hits = nullptr;
@@ -448,6 +449,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     for (EventPair& ep : pf.events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (pf.h_counters) hipHostFree(pf.h_counters);
   }
+  if (s->copy_stream) hipStreamDestroy(s->copy_stream);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -915,6 +917,75 @@ static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queu
   return fp;
 }
 
+// Host-output frames: the frame is rendered as BANDS of rows, and a finished band is copied to the caller's buffer
+// on a second stream while the next band renders — at 4K the 99.5 MB copy (~2 ms over PCIe even from pinned
+// memory; more into pageable memory, where the copy is staged) would otherwise double the time of the call.
+// Bands are row sets of the frame (block_rows = band height, n_parts = bands), so pixel-keyed jitter and the camera
+// maths are those of the whole frame and the result is identical.  Stats are summed over the bands.
+static int render_banded(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, rt_stats* stats, int32_t rows, int n_bands) {
+  const int32_t band_rows = ((rows + n_bands - 1) / n_bands + 7) / 8 * 8;
+  const int nb = (rows + band_rows - 1) / band_rows;
+  const size_t esz = fr->out_format == RT_OUT_F64 ? 8 : (fr->out_format == RT_OUT_F32 ? 4 : 1);
+  const bool fb_is_double = fr->precision == RT_FP64;
+  const size_t fsz = fb_is_double ? 8 : 4;
+  const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
+  const size_t pixels = (size_t)rows * fr->width;
+  int rc = ensure_workspace(s, pixels, pixels * 3 * esz, !native);
+  if (rc != RT_OK) return rc;
+  rc = drain(s); if (rc != RT_OK) return rc;
+  if (!s->copy_stream) HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  while ((int)s->h_slots.size() < nb) { Counters* h = nullptr; HIPCHK(hipHostMalloc(&h, sizeof(Counters))); s->h_slots.push_back(h); }
+  std::vector<rt_stats> band_stats((size_t)nb);
+  std::vector<hipEvent_t> done((size_t)nb, nullptr);
+  const DevCamera cam = to_dev_camera(camera);
+  const WorkBufs wb = own_bufs(s);
+  for (int b = 0; b < nb; ++b) {
+    rt_frame bf = *fr;
+    bf.block_rows = band_rows; bf.n_parts = nb; bf.part = b;
+    int32_t brows = 0;
+    rc = rt_rows_in_part(bf.height, bf.block_rows, bf.part, bf.n_parts, &brows);
+    if (rc != RT_OK) return rc;
+    if (nb == 1) { bf.n_parts = 1; bf.part = 0; bf.block_rows = 1; }
+    const size_t off_px = (size_t)b * band_rows * fr->width, bval = (size_t)brows * fr->width * 3;
+    PendingFrame pf;
+    pf.user = &band_stats[(size_t)b]; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
+    pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
+    pf.precision = fr->precision; pf.timing = (fr->flags & RT_FLAG_TIMING) != 0;
+    pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
+    const FrameParams fp = make_params(&bf, brows, s->cap_queue, s->cap_fix);
+    char* fb = (char*)s->d_fb + off_px * 3 * fsz;
+    rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, &bf, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, &bf, (float*)fb, &pf);
+    if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
+    char* src = fb;
+    if (!native) { src = (char*)s->d_out + off_px * 3 * esz; launch_convert(s, &pf, fb, fb_is_double, fr->out_format, src, bval); }
+    HIPCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+    done[(size_t)b] = get_event(s);
+    HIPCHK(hipEventRecord(done[(size_t)b], s->stream));
+    HIPCHK(hipStreamWaitEvent(s->copy_stream, done[(size_t)b], 0));
+    HIPCHK(hipMemcpyAsync((char*)out + off_px * 3 * esz, src, bval * esz, hipMemcpyDeviceToHost, s->copy_stream));
+    s->pending.push_back(std::move(pf));
+  }
+  rc = drain(s);                                   // waits for the render stream, folds the bands' counters
+  hipError_t ce = hipStreamSynchronize(s->copy_stream);
+  for (hipEvent_t e : done) if (e) s->event_pool.push_back(e);
+  if (ce != hipSuccess) return fail(RT_ERR_HIP, "copy of the rendered bands failed: %s", hipGetErrorString(ce));
+  if (rc != RT_OK) return rc;
+  if (stats) {
+    rt_stats t; std::memset(&t, 0, sizeof t);
+    t.levels = fr->max_depth + 1;
+    for (const rt_stats& b : band_stats) {
+      t.rays += b.rays; t.hits += b.hits; t.shadow_rays += b.shadow_rays; t.retested += b.retested;
+      t.segments = b.segments < 0 ? -1 : t.segments + b.segments;
+      for (int l = 0; l < t.levels; ++l) { t.level_rays[l] += b.level_rays[l]; t.level_hits[l] += b.level_hits[l]; }
+      t.trace_ms += b.trace_ms; t.shade_ms += b.shade_ms; t.other_ms += b.other_ms; t.total_ms += b.total_ms;
+      t.trace_launches += b.trace_launches; t.shade_launches += b.shade_launches;
+    }
+    for (int l = 0; l < t.levels; ++l) if (t.level_rays[l]) t.batches++;
+    *stats = t;
+  }
+  return RT_OK;
+}
+
 static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
                          rt_stats* stats) {
   int32_t rows = 0;
@@ -924,6 +995,11 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   HIPCHK(hipSetDevice(s->device));
   const size_t pixels = (size_t)rows * fr->width, nval = pixels * 3;
   if (pixels == 0) { if (stats) std::memset(stats, 0, sizeof *stats); return RT_OK; }
+  if (!out_is_device && fr->n_parts <= 1 && fr->jitter_mode == RT_JITTER_PIXEL_KEYED && pixels >= ((size_t)1 << 20) && rows >= 64) {
+    const char* e = getenv("RT_BANDS");
+    const int n_bands = e ? atoi(e) : 4;
+    if (n_bands > 1) return render_banded(s, camera, fr, out, stats, rows, std::min(n_bands, 16));
+  }
   const size_t esz = fr->out_format == RT_OUT_F64 ? 8 : (fr->out_format == RT_OUT_F32 ? 4 : 1);
   const bool fb_is_double = fr->precision == RT_FP64;
   const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
@@ -1054,6 +1130,17 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   if (stats) fill_stats(pf, c, stats);
   return RT_OK;
 }
+
+// Pinned host memory for output frames (hipHostMalloc): device -> host copies into it run at PCIe speed and
+// asynchronously; into pageable memory they are staged by the runtime at a fraction of that.
+extern "C" int rt_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(RT_ERR_INVALID, "rt_host_alloc: null pointer");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { *out = nullptr; return fail(RT_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+  return RT_OK;
+}
+extern "C" void rt_host_free(void* p) { if (p) hipHostFree(p); }
 
 // ------------------------------------------------------------------- utility exports -----------
 template <typename F>

@@ -23,6 +23,50 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _PinnedPool:
+    """Page-locked host buffers for output frames (rt_host_alloc).  `empty(shape, dtype)` returns an ndarray backed by
+    a pooled block; the block goes back to the pool when the array (and every view of it) has been garbage-collected, so
+    a caller that drops the previous frame before asking for the next one reuses the same pinned memory, and a caller
+    that keeps frames simply gets new blocks.  Device -> host copies into these arrays are asynchronous and run at PCIe
+    speed; into ordinary (pageable) NumPy arrays the runtime stages them at a fraction of that."""
+
+    def __init__(self):
+        self._free = {}          # nbytes -> [address, ...]
+        self.allocated = 0
+
+    def empty(self, shape, dtype):
+        import weakref
+        lib = _lib.load()
+        dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+        size = 1 << (nbytes - 1).bit_length() if nbytes > (1 << 16) else (1 << 16)     # few size classes
+        stack = self._free.setdefault(size, [])
+        if stack:
+            addr = stack.pop()
+        else:
+            p = C.c_void_p()
+            _lib.check(lib.rt_host_alloc(size, C.byref(p)))
+            addr = p.value
+            self.allocated += size
+        buf = (C.c_ubyte * size).from_address(addr)
+        weakref.finalize(buf, stack.append, addr)        # runs when the last array built on `buf` is gone
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def trim(self):
+        lib = _lib.load()
+        for stack in self._free.values():
+            while stack:
+                lib.rt_host_free(C.c_void_p(stack.pop()))
+
+
+pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """An uninitialised ndarray in page-locked host memory (see _PinnedPool); pass it as `out=` to GpuScene.render."""
+    return pinned.empty(shape, dtype)
+
+
 class GpuScene:
     """Device copy of a packed scene (rt_scene handle).  Reusable across frames; owns a HIP stream
     and the render workspace.  Use as a context manager or call close()."""
@@ -71,10 +115,12 @@ class GpuScene:
 
     # -- the hot path -------------------------------------------------------------------------
     def render(self, camera, width, height, n_shadow, max_depth, *, precision="fp64", jitter=None,
-               block_rows=1, part=0, n_parts=1, out_format=None, out_ptr=None, flags=0, stats=None, static=False):
+               block_rows=1, part=0, n_parts=1, out_format=None, out_ptr=None, flags=0, stats=None, static=False,
+               out=None):
         """Render a row set.  With `out_ptr` (a device pointer, e.g. torch_tensor.data_ptr()) the
         result stays on the GPU; otherwise a NumPy array (rows, width, 3) is returned.
-        static=True (needs out_ptr) goes through rt_render_static, the entry point that allocates nothing."""
+        static=True (needs out_ptr) goes through rt_render_static, the entry point that allocates nothing.
+        `out`: a C-contiguous host array (rows, width, 3) of the output format to fill instead of a new pinned one."""
         jit = as_jitter(jitter)
         if camera.forward is None:
             camera.setup(width / height)
@@ -104,7 +150,10 @@ class GpuScene:
                 self.last_stats = st.as_dict()
             return None
         rows = len(rows_in_part(height, block_rows, part, n_parts))
-        out = np.empty((rows, width, 3), dtype=dtype)
+        if out is None:
+            out = pinned.empty((rows, width, 3), dtype)
+        elif out.shape != (rows, width, 3) or out.dtype != dtype or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of shape {(rows, width, 3)}")
         _lib.check(self._lib.rt_render(self._h, C.byref(cam), C.byref(fr), _ptr(out), 0, C.byref(st)))
         self.last_stats = st.as_dict()
         return out
@@ -134,15 +183,49 @@ def _rays(origins, dirs):
     return o, d
 
 
+_scene_cache = {}       # (device, digest of the packed arrays) -> GpuScene; a couple of entries, oldest dropped first
+
+
+def _cached_scene(materials, surfaces, lights, background_color, device):
+    """The GpuScene of these objects, kept across render_hip calls: uploading the scene and growing the render
+    workspace (GBs of queues at 4K) costs far more than a frame.  Keyed by the CONTENT of the packed arrays, so edited
+    objects get a new device copy."""
+    import hashlib
+    packed = pack_scene(materials, surfaces, lights, background_color)
+    h = hashlib.blake2b(digest_size=16)
+    for a in (packed.surf_type, packed.surf_data, packed.surf_material, packed.materials, packed.lights,
+              np.asarray(packed.background, dtype=np.float64)):
+        h.update(np.ascontiguousarray(a).tobytes()); h.update(b"|")
+    import os
+    # (the A/B switches rt_scene_create reads from the environment are part of what the handle is)
+    env = tuple(os.environ.get(k) for k in ("RT_ACCEL", "RT_BVH_LEAF", "RT_BVH_FANOUT", "RT_BVH_ORDER", "RT_SHADE", "RT_SORT_HITS"))
+    key = (int(device), h.digest(), env)
+    gs = _scene_cache.get(key)
+    if gs is None or getattr(gs, "_h", None) is None:
+        while len(_scene_cache) >= 2:
+            _scene_cache.pop(next(iter(_scene_cache))).close()
+        gs = _scene_cache[key] = GpuScene(packed, device)
+    return gs
+
+
+def clear_scene_cache():
+    while _scene_cache:
+        _scene_cache.pop(next(iter(_scene_cache))).close()
+
+
 def render_hip(camera, scene_settings, materials, surfaces, lights, width, height, *,
-               precision="fp64", jitter=None, device=0, stats=None, verbose=True, sequential=False):
+               precision="fp64", jitter=None, device=0, stats=None, verbose=True, sequential=False, out_dtype=np.float64):
     """Drop-in for the reference's render_vectorized: returns (height, width, 3) float64 unclipped
     linear radiance and, like the reference, calls camera.setup(width / height) first.
 
     Keyword-only extras: precision "fp64" (1e-9 relative parity) or "fp32" (fast mode, <= 1/255 per
     8-bit channel); jitter = int seed | ("pixel", seed) | ("numpy", seed); stats = dict to fill;
     sequential=True renders with the semantics of the reference's per-pixel `render`
-    (ray_tracer.py:398-434; differences listed at RT_FLAG_SEQUENTIAL in include/rt_hip.h).
+    (ray_tracer.py:398-434; differences listed at RT_FLAG_SEQUENTIAL in include/rt_hip.h);
+    out_dtype = np.float64 (the reference's return type), np.float32 (half the bytes over PCIe; the natural
+    format of precision="fp32") or np.uint8 (the reference's save_image quantisation, ray_tracer.py:606-608).
+    The returned array lives in pooled page-locked memory (see _PinnedPool); the device copy of the scene and
+    its workspace are kept for the next call with the same scene (clear_scene_cache() drops them).
     """
     t0 = time.time()
     camera.setup(width / height)
@@ -151,16 +234,17 @@ def render_hip(camera, scene_settings, materials, surfaces, lights, width, heigh
     if verbose:
         print(f"Max depth: {max_depth}, Shadow rays: {n_shadow}x{n_shadow}={n_shadow * n_shadow} per light")
         print(f"HIP rendering {width}x{height} = {width * height} rays ({precision})...")
-    with GpuScene.from_objects(materials, surfaces, lights, scene_settings.background_color, device) as gs:
-        img = gs.render(camera, width, height, n_shadow, max_depth, precision=precision, jitter=jitter,
-                        flags=_lib.RT_FLAG_SEQUENTIAL if sequential else 0)
-        st = gs.last_stats
+    fmt = {np.dtype(np.float64): "f64", np.dtype(np.float32): "f32", np.dtype(np.uint8): "u8"}[np.dtype(out_dtype)]
+    gs = _cached_scene(materials, surfaces, lights, scene_settings.background_color, device)
+    img = gs.render(camera, width, height, n_shadow, max_depth, precision=precision, jitter=jitter, out_format=fmt,
+                    flags=_lib.RT_FLAG_SEQUENTIAL if sequential else 0)
+    st = gs.last_stats
     if stats is not None:
         stats.update(st)
     if verbose:
         print(f"HIP rendering complete in {time.time() - t0:.3f}s ({st['rays']} total rays, "
               f"{st['shadow_rays']} shadow rays)")
-    return np.ascontiguousarray(img, dtype=np.float64)
+    return img
 
 
 render_vectorized = render_hip   # same name as the reference entry point
