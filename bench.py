@@ -350,7 +350,7 @@ def main():
             out["boundary_ms"] = round(min(bt[1:]), 4)
             out["boundary"] = {"call": f"render_hip(camera, scene_settings, materials, surfaces, lights, {W}, {H}, precision='{precision}', out_dtype={np.dtype(out_dt).name})",
                                "ms": [round(x, 3) for x in bt], "bytes_to_host": int(W * H * 3 * np.dtype(out_dt).itemsize),
-                               "note": "wall time of the Python call: pack + cached device scene + frame rendered in 4 row bands, each copied to pinned host memory while the next renders"}
+                               "note": "wall time of the Python call: pack + cached device scene + frame rendered in 3 row bands, each copied to pinned host memory while the next renders"}
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(args.workload, gs, cam, st, mats, surfs, lights, W, H, precision)
             out["cpu_baseline"] = base

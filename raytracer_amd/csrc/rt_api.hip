@@ -997,7 +997,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (pixels == 0) { if (stats) std::memset(stats, 0, sizeof *stats); return RT_OK; }
   if (!out_is_device && fr->n_parts <= 1 && fr->jitter_mode == RT_JITTER_PIXEL_KEYED && pixels >= ((size_t)1 << 20) && rows >= 64) {
     const char* e = getenv("RT_BANDS");
-    const int n_bands = e ? atoi(e) : 4;
+    const int n_bands = e ? atoi(e) : 3;
     if (n_bands > 1) return render_banded(s, camera, fr, out, stats, rows, std::min(n_bands, 16));
   }
   const size_t esz = fr->out_format == RT_OUT_F64 ? 8 : (fr->out_format == RT_OUT_F32 ? 4 : 1);

@@ -395,12 +395,39 @@ __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int 
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
-  const float ofx = (float)o.x, ofy = (float)o.y, ofz = (float)o.z;
+  // The conservative fp32 tests below work relative to a walk origin ow = o + t0*d.  For an origin far outside the
+  // hierarchy's bounds (a bounce ray leaving a floor hit 1e5 units away) t0 moves it to where the ray reaches the
+  // bounds (computed in fp64): the fp32 slack, which scales with the origin's coordinates, would otherwise swallow
+  // every node, and the walk would run the exact test on every record.  Results are unchanged (the exact tests use
+  // o and d themselves); a ray that misses the bounds altogether skips the hierarchy.
+  double t0 = 0.0;
+  bool skip_tree = false;        // (no early return: with WAVE all 64 lanes take part in the wave-level steps below)
+  {
+    const double far_ = fabs(o.x) + fabs(o.y) + fabs(o.z);
+    const double ext = (double)(ac.hi[0] - ac.lo[0]) + (double)(ac.hi[1] - ac.lo[1]) + (double)(ac.hi[2] - ac.lo[2]);
+    const bool outside = (o.x < ac.lo[0]) | (o.x > ac.hi[0]) | (o.y < ac.lo[1]) | (o.y > ac.hi[1]) | (o.z < ac.lo[2]) | (o.z > ac.hi[2]);
+    if (outside & (far_ > 4.0 * ext + 16.0)) {
+      double tn = 0.0, tf = RT_INF;
+      const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+      const double mg = 1e-3 * (ext + 1.0);                   // margin around the bounds
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        if (fabs(dd[ax]) > 1e-300) {
+          const double a_ = ((double)ac.lo[ax] - mg - oo[ax]) / dd[ax], b_ = ((double)ac.hi[ax] + mg - oo[ax]) / dd[ax];
+          tn = fmax(tn, fmin(a_, b_)); tf = fmin(tf, fmax(a_, b_));
+        } else if (oo[ax] < (double)ac.lo[ax] - mg || oo[ax] > (double)ac.hi[ax] + mg) tf = -1.0;
+      }
+      if (!(tn <= tf)) skip_tree = true;                     // misses the hierarchy's bounds: planes only
+      else t0 = tn;
+    }
+  }
+  const float ofx = (float)(o.x + t0 * d.x), ofy = (float)(o.y + t0 * d.y), ofz = (float)(o.z + t0 * d.z);
   float ux = (float)d.x, uy = (float)d.y, uz = (float)d.z;
   const float len2 = fmaf(uz, uz, fmaf(uy, uy, ux * ux));
   const float inv = 1.0f / sqrtf(len2), len = len2 * inv;        // directions need not be unit (rt_nearest_hit)
   ux *= inv; uy *= inv; uz *= inv;
-  float tmax_u = best < 1e30 ? (float)best * len * 1.00001f + 1e-5f : 3.0e38f;
+  float tmax_u = best < 1e30 ? (float)((best - t0) * len) * 1.00001f + 1e-5f : 3.0e38f;
+  if (skip_tree) tmax_u = -1.0f;       // every node / record test below fails; also when a plane is hit before the bounds (tmax_u < 0)
   // slab test of the node boxes: inflating a box by dl in space covers an error of dl*|1/u| in t
   const float ix = fabsf(ux) > 1e-20f ? 1.0f / ux : 1e30f, iy = fabsf(uy) > 1e-20f ? 1.0f / uy : 1e30f,
               iz = fabsf(uz) > 1e-20f ? 1.0f / uz : 1e30f;
@@ -419,7 +446,7 @@ __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int 
     const int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) {
       best = t; bk = k; borig = og;
-      tmax_u = (float)best * len * 1.00001f + 1e-5f;
+      tmax_u = (float)((best - t0) * len) * 1.00001f + 1e-5f;
     }
   };
   int n_wl = -1;

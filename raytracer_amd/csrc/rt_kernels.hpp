@@ -214,7 +214,7 @@ __device__ __forceinline__ RayIn load_ray(int level, uint32_t slot, const DevCam
 constexpr int TRACE_CHUNK = 1024;
 
 template <typename FB, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE ? 1 : 4))) void k_trace(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                  HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
   __shared__ BvhNode s_nodes[LDS_SCENE ? 1 : LDS_NODES];

@@ -12,6 +12,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("RT_BANDS", "1")      # kernel-time probe: one frame = one set of launches (no row bands for the host copy)
 
 import numpy as np  # noqa: E402
 
