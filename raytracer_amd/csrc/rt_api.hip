@@ -135,6 +135,52 @@ struct BvhBuilder {
   }
 };
 
+// Heap-layout complete binary tree over the records [first, first+count) (Accel::hnodes): leaf q of the 2^L leaves
+// owns records [first + 8q, first + 8q + 8), slots beyond the range get empty boxes.  Inner nodes remember the axis
+// along which their children's centres differ most and which child lies on the low side (front-to-back order).
+struct HeapTree { int L = 0, base = 0, first = 0, count = 0; };
+HeapTree build_heap(const std::vector<Prim>& prims, int first, int count, std::vector<float>& hn, std::vector<uint8_t>& ha) {
+  HeapTree t; t.first = first; t.count = count; t.base = (int)ha.size();
+  if (count <= 0) return t;
+  const int n_leaves = (count + 7) / 8;
+  while ((1 << t.L) < n_leaves) ++t.L;
+  const int n = (2 << t.L) - 1, first_leaf = (1 << t.L) - 1;
+  std::vector<BoxD> box(n);
+  for (int i = n - 1; i >= 0; --i) {
+    BoxD& b = box[i];
+    for (int k = 0; k < 3; ++k) { b.lo[k] = 1e300; b.hi[k] = -1e300; }
+    uint8_t info = 0;
+    if (i >= first_leaf) {
+      const int q = i - first_leaf;
+      for (int r = 8 * q; r < std::min(count, 8 * q + 8); ++r) BvhBuilder::grow(&b, prim_box(prims[first + r]));
+    } else {
+      const BoxD& l = box[2 * i + 1]; const BoxD& r = box[2 * i + 2];
+      BvhBuilder::grow(&b, l); BvhBuilder::grow(&b, r);
+      if (l.lo[0] <= l.hi[0] && r.lo[0] <= r.hi[0]) {
+        int axis = 0; double best = -1.0, diff[3];
+        for (int k = 0; k < 3; ++k) { diff[k] = (r.lo[k] + r.hi[k]) - (l.lo[k] + l.hi[k]); if (std::fabs(diff[k]) > best) { best = std::fabs(diff[k]); axis = k; } }
+        info = (uint8_t)(axis | (diff[axis] >= 0.0 ? 4 : 0));
+      }
+    }
+    for (int k = 0; k < 3; ++k) {                                      // round outward; empty stays empty
+      float lo = (float)b.lo[k], hi = (float)b.hi[k];
+      if (b.lo[k] > b.hi[k]) { lo = 3.0e38f; hi = -3.0e38f; }
+      else {
+        if ((double)lo > b.lo[k]) lo = std::nextafter(lo, -INFINITY);
+        if ((double)hi < b.hi[k]) hi = std::nextafter(hi, INFINITY);
+        if (!(lo == lo)) lo = -3.0e38f;
+        if (!(hi == hi)) hi = 3.0e38f;
+        lo = std::max(lo, -3.0e38f); hi = std::min(hi, 3.0e38f);
+      }
+      if ((int)hn.size() < 6 * (t.base + n)) hn.resize(6 * (size_t)(t.base + n));
+      hn[6 * (size_t)(t.base + i) + k] = lo; hn[6 * (size_t)(t.base + i) + 3 + k] = hi;
+    }
+    if ((int)ha.size() < t.base + n) ha.resize(t.base + n);
+    ha[t.base + i] = info;
+  }
+  return t;
+}
+
 // Morton order of the records [first, first+count) by bound centre (stable for equal codes).
 void morton_sort(std::vector<Prim>& prims, int first, int count) {
   if (count <= 8) return;
@@ -232,6 +278,8 @@ struct rt_scene {
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
   int32_t* d_cut = nullptr;
   BvhNode* d_nodes = nullptr; float4* d_pbound = nullptr;   // culling hierarchy (large scenes only)
+  float* d_hnodes = nullptr; uint8_t* d_haxis = nullptr;    // heap-layout trees for nearest-hit walks
+  bool pool_trace = false;                                   // bounce levels through k_trace_pool (needs the heap trees)
   bool all_opaque = true;
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
@@ -314,6 +362,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   std::vector<int32_t> cut;        // <= 64 nodes covering both trees: entry points of the wave-level scan
   std::vector<BvhNode> nodes;
   std::vector<float4> pbound;
+  std::vector<float> hn; std::vector<uint8_t> ha; HeapTree heap[2];
   {
     const char* e = getenv("RT_ACCEL");
     const bool want = !(e && e[0] == '0');
@@ -349,6 +398,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         }
         if (!expanded || next.size() > 64) break;
         cut.swap(next);
+      }
+      if (!(getenv("RT_BVH_HEAP") && atoi(getenv("RT_BVH_HEAP")) == 0)) {
+        heap[0] = build_heap(prims, 0, cnt[0], hn, ha);
+        heap[1] = build_heap(prims, cnt[0] + cnt[1], cnt[2], hn, ha);
       }
       pbound.resize(prims.size());
       for (size_t i = 0; i < prims.size(); ++i)
@@ -396,7 +449,16 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     HIPCHK_S(hipMalloc(&s->d_cut, 64 * sizeof(int32_t)));
     HIPCHK_S(hipMemcpy(s->d_cut, cut.data(), cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  if (!ha.empty()) {
+    HIPCHK_S(hipMalloc(&s->d_hnodes, hn.size() * sizeof(float)));
+    HIPCHK_S(hipMalloc(&s->d_haxis, ha.size()));
+    HIPCHK_S(hipMemcpy(s->d_hnodes, hn.data(), hn.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMemcpy(s->d_haxis, ha.data(), ha.size(), hipMemcpyHostToDevice));
+  }
 #undef HIPCHK_S
+  s->pool_trace = s->d_hnodes != nullptr && !(getenv("RT_TRACE_POOL") && atoi(getenv("RT_TRACE_POOL")) == 0);
+  s->ds.ac.hnodes = s->d_hnodes; s->ds.ac.haxis = s->d_haxis; s->ds.ac.n_hnodes = (int)ha.size(); s->ds.ac.lds_hnodes = -1;
+  for (int k = 0; k < 2; ++k) { s->ds.ac.hL[k] = heap[k].L; s->ds.ac.hbase[k] = heap[k].base; s->ds.ac.hfirst[k] = heap[k].first; s->ds.ac.hcount[k] = heap[k].count; }
   s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.lds_nodes = -1;
   s->ds.ac.cut = s->d_cut; s->ds.ac.n_cut = (int)cut.size(); s->ds.ac.pad = 0;
   for (int k = 0; k < 3; ++k) { s->ds.ac.lo[k] = accel_lo[k]; s->ds.ac.hi[k] = accel_hi[k]; }
@@ -440,6 +502,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_lights) hipFree(s->d_lights);
   if (s->d_nodes) hipFree(s->d_nodes);
   if (s->d_pbound) hipFree(s->d_pbound);
+  if (s->d_hnodes) hipFree(s->d_hnodes);
+  if (s->d_haxis) hipFree(s->d_haxis);
   if (s->d_cut) hipFree(s->d_cut);
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
@@ -530,6 +594,16 @@ static int drain(rt_scene* s) {
       rc = fail(RT_ERR_QUEUE_OVERFLOW, "re-test queue overflow (a sub-queue holds %zu (hit, light) pairs, capacity %zu): a blocking "
                 "rt_render call grows the queue and retries by itself", worst, s->cap_fix / FIX_QUEUES);
     }
+#ifdef RT_DEBUG_KERNEL
+    if (getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 21))) {
+      unsigned long long w[8] = {0}, z[8] = {0};
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_walk_dbg), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_walk_dbg), z, sizeof z);
+      const double nw = (double)std::max(1ull, w[6]);
+      fprintf(stderr, "[rt debug] per-lane heap walks since the last frame: %llu waves; per wave: %.1f node steps (lanes' mean %.1f), %.1f leaves (%.1f), "
+              "%.1f exact tests (%.1f), %.0f cycles\n", w[6], w[0] / nw, w[1] / nw / 64, w[2] / nw, w[3] / nw / 64, w[4] / nw, w[5] / nw / 64, w[7] / nw);
+    }
+#endif
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))
       fprintf(stderr, "[rt debug] k_shade_ls (wave, light) pairs: %llu total, %llu without a sample loop\n",
               (unsigned long long)(c.queries >> 32), (unsigned long long)(c.queries & 0xFFFFFFFFull));
@@ -666,6 +740,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
     {
       Timed t(s, pf, 0);
       if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
+      else if (level >= 1 && s->pool_trace) hipLaunchKernelGGL((k_trace_pool<FB>), dim3(s->num_cu * 4), dim3(BLOCK), 0, s->stream, s->ds, fp, level, cur, wb.hits, wb.counters, fb);
       else hipLaunchKernelGGL((k_trace<FB, false>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
     }
     const HitRec* level_hits = wb.hits;

@@ -122,10 +122,21 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
 // dependent loads, LDS latency is several times shorter than L2's.
 constexpr int LDS_NODES = 980;      // (k_trace's nodes + hit staging + wave lists then fit four workgroups per CU)
 template <bool LDS_SCENE>
-__device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
+__device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds, bool heap = false) {
   Accel a = sc.ac;
-  a.lds_nodes = -1;
-  if (LDS_SCENE) { a.n_nodes = 0; return a; }
+  a.lds_nodes = -1; a.lds_hnodes = -1;
+  if (LDS_SCENE) { a.n_nodes = 0; a.hnodes = nullptr; return a; }
+  if (heap && a.hnodes != nullptr && (size_t)a.n_hnodes * 25 <= (size_t)LDS_NODES * sizeof(BvhNode)) {
+    // the heap trees instead of the skip-link nodes (per-lane nearest-hit walks: k_trace below level 0)
+    const int words = a.n_hnodes * 6;
+    float* dst = reinterpret_cast<float*>(lds);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = a.hnodes[i];
+    uint8_t* dsta = reinterpret_cast<uint8_t*>(lds) + 24 * a.n_hnodes;
+    for (int i = threadIdx.x; i < a.n_hnodes; i += blockDim.x) dsta[i] = a.haxis[i];
+    __syncthreads();
+    a.lds_hnodes = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) BvhNode*)lds;
+    return a;
+  }
   if (a.n_nodes <= 0 || a.n_nodes > LDS_NODES) return a;
   const int words = a.n_nodes * (int)(sizeof(BvhNode) / 16);
   const uint4* src = reinterpret_cast<const uint4*>(a.nodes);
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
   __shared__ uint32_t s_count, s_base;
   __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];      // per-wave leaf lists (nearest_accel<true>)
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
-  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes, level > 0 || (fp.debug & 4096u));
   // wave-level scan for the camera rays only (8x8 pixel tiles: one origin, a thin cone; measured 1.13 -> 0.74 ms on
   // the synthetic 4K frame).  The deeper levels' waves mix transmitted and reflected rays of many surfaces: their
   // cones are too wide, and the attempt costs them ~3 %.  RT_DEBUG_STATS=4096: per-lane walks everywhere (A/B).
@@ -321,6 +332,155 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
       else C->overflow = 1u;
     }
     __syncthreads();
+  }
+}
+
+// k_trace for the bounce levels of large scenes.  Bounce rays of one wave take very different paths through the
+// hierarchy (measured on the synthetic 4608-object scene: 44 node steps per ray, but 118 per wave, which waits for
+// its slowest lane), so here a wave keeps a POOL of rays instead of one ray per lane: a lane whose walk has ended
+// writes its result and, once enough lanes are idle, takes the next ray of the pool while the others carry on.
+// Pools are chunks of POOL_CHUNK consecutive queue slots, grabbed with one atomic on Counters::work_trace[level].
+// Hits are gathered per wave in LDS and appended to the hit list 64+ at a time (one global atomic each), so nothing
+// in the main loop needs a workgroup barrier.  Results are those of k_trace (same exact tests, same (t, orig) rule);
+// only the order of the hit list differs, and no consumer depends on it.
+constexpr int POOL_CHUNK = 512;
+#ifndef RT_POOL_REFILL
+#define RT_POOL_REFILL 24
+#endif
+#ifndef RT_POOL_MIN_STEP
+#define RT_POOL_MIN_STEP 12
+#endif
+constexpr int POOL_REFILL = RT_POOL_REFILL;     // idle lanes that trigger a refill
+constexpr int POOL_MIN_STEP = RT_POOL_MIN_STEP; // node steps stop when fewer lanes than this are still stepping (the rest wait at their leaves)
+template <typename FB>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_trace_pool(DevScene sc, FrameParams fp, int level, RayQueue q,
+                                                 HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
+  __shared__ BvhNode s_nodes[LDS_NODES];
+  __shared__ HitRec s_whits[BLOCK / 64][128];
+  __shared__ uint32_t s_segfirst[NSEG + 1];
+  const Prim* P = sc.prims;
+  const Accel ac = stage_accel<false>(sc, s_nodes, true);
+  const uint32_t seg_cap = fp.queue_cap / NSEG;
+  if (threadIdx.x < 64) {                          // lane q: segment q; inclusive scans over the wave (as in k_trace)
+    const uint32_t raw = C->segcnt[level & 1][threadIdx.x * 32];
+    const uint32_t nq_ = min(raw, seg_cap);
+    uint32_t ch = (nq_ + POOL_CHUNK - 1) / POOL_CHUNK, tot = nq_, worst = raw;
+#pragma unroll
+    for (int o_ = 1; o_ < 64; o_ <<= 1) {
+      const uint32_t a = __shfl_up(ch, o_), b = __shfl_up(tot, o_);
+      if ((int)threadIdx.x >= o_) { ch += a; tot += b; }
+      worst = max(worst, (uint32_t)__shfl_xor((int)worst, o_));
+    }
+    s_segfirst[threadIdx.x + 1] = ch;
+    if (threadIdx.x == 0) s_segfirst[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 63) { C->n_rays[level] = tot; atomicMax(&C->seg_need, worst); }
+  }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < NSEG; i += BLOCK) C->segcnt[(level + 1) & 1][i * 32] = 0u;
+    if (threadIdx.x < NSTRIPE) C->stripes[threadIdx.x * 32] = 0u;
+    if (threadIdx.x == 0) C->stripes_done = 0u;
+  }
+  __syncthreads();
+  const uint32_t n_chunks = s_segfirst[NSEG];
+  const int lane = (int)__lane_id();
+  HitRec* whits = s_whits[threadIdx.x >> 6];
+  uint32_t n_wh = 0;                               // hits waiting in the wave's buffer (wave-uniform)
+  uint32_t pool_next = 0, pool_end = 0;            // slots of the current pool not handed out yet (wave-uniform)
+  bool exhausted = false;                          // no more chunks (wave-uniform)
+  bool busy = false;                               // this lane holds a ray
+  PoolRay pr; pr.tree = 2; pr.idx = 0; pr.trail = 0u; pr.bk = -1; pr.best = RT_INF;
+  uint32_t slot = 0;
+  for (;;) {
+    // ---- refill: idle lanes take the next rays of the pool
+    const unsigned long long idle = __ballot(!busy);
+    const int n_idle = __popcll(idle);
+    if (n_idle == 64 || (n_idle >= POOL_REFILL && !exhausted)) {
+      int want = n_idle;                           // idle lanes still without a ray (the lowest ones are served first)
+      while (want > 0 && !exhausted) {
+        if (pool_next >= pool_end) {               // next chunk
+          uint32_t chunk = 0;
+          if (lane == 0) chunk = atomicAdd(&C->work_trace[level], 1u);
+          chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+          if (chunk >= n_chunks) { exhausted = true; break; }
+          int lo_ = 0, hi_ = NSEG;                 // last segment whose first chunk id is <= chunk
+          while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (s_segfirst[mid] <= chunk) lo_ = mid; else hi_ = mid; }
+          uint32_t nq_ = C->segcnt[level & 1][lo_ * 32]; if (nq_ > seg_cap) nq_ = seg_cap;
+          nq_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq_);
+          pool_next = (uint32_t)lo_ * seg_cap + (chunk - s_segfirst[lo_]) * POOL_CHUNK;
+          pool_end = min(pool_next + (uint32_t)POOL_CHUNK, (uint32_t)lo_ * seg_cap + nq_);
+        }
+        const unsigned long long need = __ballot(!busy);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        const uint32_t avail = pool_end - pool_next;
+        if (!busy && rank < avail) {
+          slot = pool_next + rank;
+          const d3 o = mk3(q.ox[slot], q.oy[slot], q.oz[slot]);
+          const d3 d = mk3(q.dx[slot], q.dy[slot], q.dz[slot]);
+          pr.begin(P, sc.nS, sc.nP, ac, o, d, fp.plane_thr);
+          busy = true;
+        }
+        const uint32_t took = min((uint32_t)want, avail);
+        pool_next += took;
+        want -= (int)took;
+      }
+    }
+    if (__ballot(busy) == 0ull) break;             // every ray of every chunk this wave took is done
+    // ---- node steps until every busy lane holds a leaf or has finished, then the leaves together
+    int nj = 0;
+    int rec = -1;
+    if (busy) rec = pr.to_next_leaf(ac, &nj, POOL_MIN_STEP);
+    if (rec >= 0) {
+      RT_WALK_COUNT(2);
+      uint32_t cand = 0;
+#pragma unroll
+      for (int h = 0; h < 8; h += 4) {
+        if (h > 0 && nj <= h) break;
+        float4 b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = ac.pbound[rec + (h + j < nj ? h + j : 0)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cand |= (h + j < nj && pr.may(b[j])) ? (1u << (h + j)) : 0u;
+      }
+      while (cand) {
+        RT_WALK_COUNT(4);
+        const int j = __ffs((int)cand) - 1;
+        cand &= cand - 1;
+        pr.exact(P, sc.nS, rec + j);
+      }
+    }
+    // ---- finished walks: miss -> background, hit -> the wave's buffer
+    const bool fin = busy && rec == -1 && pr.tree == 2;
+    const bool hit = fin && pr.bk >= 0;
+    if (fin && !hit) {
+      const uint32_t lp = q.pix[slot];
+      fb_add(fb, lp, q.wx[slot] * sc.bg[0], q.wy[slot] * sc.bg[1], q.wz[slot] * sc.bg[2]);   // :500-502
+    }
+    if (fin) busy = false;
+    const unsigned long long mh = __ballot(hit);
+    if (mh) {
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+      if (hit) { HitRec h; h.slot = slot; h.prim = pr.bk; h.t = pr.best; whits[n_wh + r] = h; }
+      n_wh += (uint32_t)__popcll(mh);
+      if (n_wh >= 64u) {
+        uint32_t gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&C->n_hits[level], n_wh);
+        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+        for (uint32_t i = (uint32_t)lane; i < n_wh; i += 64u) {
+          if (gbase + i < fp.queue_cap) hits[gbase + i] = whits[i];
+          else C->overflow = 1u;
+        }
+        n_wh = 0;
+      }
+    }
+  }
+  if (n_wh > 0u) {
+    uint32_t gbase = 0;
+    if (lane == 0) gbase = atomicAdd(&C->n_hits[level], n_wh);
+    gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+    for (uint32_t i = (uint32_t)lane; i < n_wh; i += 64u) {
+      if (gbase + i < fp.queue_cap) hits[gbase + i] = whits[i];
+      else C->overflow = 1u;
+    }
   }
 }
 
