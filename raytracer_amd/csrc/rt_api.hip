@@ -135,48 +135,79 @@ struct BvhBuilder {
   }
 };
 
-// Heap-layout complete binary tree over the records [first, first+count) (Accel::hnodes): leaf q of the 2^L leaves
-// owns records [first + 8q, first + 8q + 8), slots beyond the range get empty boxes.  Inner nodes remember the axis
-// along which their children's centres differ most and which child lies on the low side (front-to-back order).
-struct HeapTree { int L = 0, base = 0, first = 0, count = 0; };
-HeapTree build_heap(const std::vector<Prim>& prims, int first, int count, std::vector<float>& hn, std::vector<uint8_t>& ha) {
-  HeapTree t; t.first = first; t.count = count; t.base = (int)ha.size();
-  if (count <= 0) return t;
-  const int n_leaves = (count + 7) / 8;
-  while ((1 << t.L) < n_leaves) ++t.L;
-  const int n = (2 << t.L) - 1, first_leaf = (1 << t.L) - 1;
-  std::vector<BoxD> box(n);
-  for (int i = n - 1; i >= 0; --i) {
-    BoxD& b = box[i];
+// The nearest-hit tree (Accel::hpair): a complete binary tree in heap layout over the groups of <= 8 consecutive records
+// of one type.  Built top down: the subtree sizes are fixed by the heap shape, the groups of a node are split by an
+// nth_element of their centres along the axis that gives the smallest (area x count) sum of the two child boxes.
+struct HeapTree {
+  std::vector<float> pair;        // [max(n_groups - 1, 1)][12]
+  std::vector<uint8_t> axis;      // [max(n_groups - 1, 1)]
+  std::vector<uint32_t> leaf;     // [n_groups]
+  int n_groups = 0, n_sphere_groups = 0;
+};
+static double box_area(const BoxD& b) {
+  if (b.lo[0] > b.hi[0]) return 0.0;
+  const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+  return x * y + y * z + z * x;
+}
+static void heap_build_node(int i, int n_g, uint32_t* gl, int m, const std::vector<int>& leaves_below, const std::vector<BoxD>& gbox,
+                            std::vector<BoxD>& nbox, HeapTree& t) {
+  BoxD& b = nbox[i];
+  for (int k = 0; k < 3; ++k) { b.lo[k] = 1e300; b.hi[k] = -1e300; }
+  if (i >= n_g - 1) { t.leaf[i - (n_g - 1)] = gl[0]; b = gbox[gl[0]]; return; }
+  const int nl = leaves_below[2 * i + 1];
+  int best_axis = 0; double best_cost = 1e300;
+  std::vector<uint32_t> tmp(gl, gl + m), best_order;
+  for (int axis = 0; axis < 3; ++axis) {
+    std::copy(gl, gl + m, tmp.begin());
+    std::nth_element(tmp.begin(), tmp.begin() + nl, tmp.end(), [&](uint32_t a, uint32_t c) {
+      const double ca = gbox[a].lo[axis] + gbox[a].hi[axis], cc = gbox[c].lo[axis] + gbox[c].hi[axis];
+      return ca < cc || (ca == cc && a < c); });
+    BoxD l, r;
+    for (int k = 0; k < 3; ++k) { l.lo[k] = r.lo[k] = 1e300; l.hi[k] = r.hi[k] = -1e300; }
+    for (int q = 0; q < nl; ++q) BvhBuilder::grow(&l, gbox[tmp[q]]);
+    for (int q = nl; q < m; ++q) BvhBuilder::grow(&r, gbox[tmp[q]]);
+    const double cost = box_area(l) * nl + box_area(r) * (m - nl);
+    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_order = tmp; }
+  }
+  std::copy(best_order.begin(), best_order.end(), gl);
+  heap_build_node(2 * i + 1, n_g, gl, nl, leaves_below, gbox, nbox, t);
+  heap_build_node(2 * i + 2, n_g, gl + nl, m - nl, leaves_below, gbox, nbox, t);
+  BvhBuilder::grow(&b, nbox[2 * i + 1]); BvhBuilder::grow(&b, nbox[2 * i + 2]);
+  t.axis[i] = (uint8_t)(best_axis | 4);          // the left child holds the lower centres: first for d[axis] > 0
+}
+HeapTree build_heap(const std::vector<Prim>& prims, int nS, int box_first, int nB) {
+  HeapTree t;
+  t.n_sphere_groups = (nS + 7) / 8;
+  const int n_g = t.n_sphere_groups + (nB + 7) / 8;
+  t.n_groups = n_g;
+  if (n_g <= 0) return t;
+  std::vector<BoxD> gbox(n_g);
+  for (int g = 0; g < n_g; ++g) {
+    BoxD& b = gbox[g];
     for (int k = 0; k < 3; ++k) { b.lo[k] = 1e300; b.hi[k] = -1e300; }
-    uint8_t info = 0;
-    if (i >= first_leaf) {
-      const int q = i - first_leaf;
-      for (int r = 8 * q; r < std::min(count, 8 * q + 8); ++r) BvhBuilder::grow(&b, prim_box(prims[first + r]));
-    } else {
-      const BoxD& l = box[2 * i + 1]; const BoxD& r = box[2 * i + 2];
-      BvhBuilder::grow(&b, l); BvhBuilder::grow(&b, r);
-      if (l.lo[0] <= l.hi[0] && r.lo[0] <= r.hi[0]) {
-        int axis = 0; double best = -1.0, diff[3];
-        for (int k = 0; k < 3; ++k) { diff[k] = (r.lo[k] + r.hi[k]) - (l.lo[k] + l.hi[k]); if (std::fabs(diff[k]) > best) { best = std::fabs(diff[k]); axis = k; } }
-        info = (uint8_t)(axis | (diff[axis] >= 0.0 ? 4 : 0));
+    const bool sph = g < t.n_sphere_groups;
+    const int j = sph ? g : g - t.n_sphere_groups, first = (sph ? 0 : box_first) + 8 * j, n = std::min(8, (sph ? nS : nB) - 8 * j);
+    for (int r = 0; r < n; ++r) BvhBuilder::grow(&b, prim_box(prims[first + r]));
+  }
+  const int n_nodes = 2 * n_g - 1, n_inner = n_g - 1;
+  std::vector<int> leaves_below(n_nodes);
+  for (int i = n_nodes - 1; i >= 0; --i) leaves_below[i] = i >= n_inner ? 1 : leaves_below[2 * i + 1] + leaves_below[2 * i + 2];
+  std::vector<BoxD> nbox(n_nodes);
+  std::vector<uint32_t> gl(n_g);
+  for (int g = 0; g < n_g; ++g) gl[g] = (uint32_t)g;
+  t.leaf.resize(n_g); t.axis.assign(std::max(n_inner, 1), 0); t.pair.assign((size_t)std::max(n_inner, 1) * 12, 0.0f);
+  heap_build_node(0, n_g, gl.data(), n_g, leaves_below, gbox, nbox, t);
+  auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafter(f, -INFINITY); if (!(f == f)) f = -3.0e38f; return std::max(f, -3.0e38f); };
+  auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafter(f, INFINITY); if (!(f == f)) f = 3.0e38f; return std::min(f, 3.0e38f); };
+  for (int i = 0; i < std::max(n_inner, 1); ++i) {
+    float* q = &t.pair[(size_t)i * 12];
+    for (int c = 0; c < 2; ++c) {
+      const bool have = i < n_inner;
+      for (int k = 0; k < 3; ++k) {
+        q[2 * k + c] = have ? down(nbox[2 * i + 1 + c].lo[k]) : 3.0e38f;            // (no inner node: an empty pair, never loaded for a test)
+        q[6 + 2 * k + c] = have ? up(nbox[2 * i + 1 + c].hi[k]) : -3.0e38f;
       }
     }
-    for (int k = 0; k < 3; ++k) {                                      // round outward; empty stays empty
-      float lo = (float)b.lo[k], hi = (float)b.hi[k];
-      if (b.lo[k] > b.hi[k]) { lo = 3.0e38f; hi = -3.0e38f; }
-      else {
-        if ((double)lo > b.lo[k]) lo = std::nextafter(lo, -INFINITY);
-        if ((double)hi < b.hi[k]) hi = std::nextafter(hi, INFINITY);
-        if (!(lo == lo)) lo = -3.0e38f;
-        if (!(hi == hi)) hi = 3.0e38f;
-        lo = std::max(lo, -3.0e38f); hi = std::min(hi, 3.0e38f);
-      }
-      if ((int)hn.size() < 6 * (t.base + n)) hn.resize(6 * (size_t)(t.base + n));
-      hn[6 * (size_t)(t.base + i) + k] = lo; hn[6 * (size_t)(t.base + i) + 3 + k] = hi;
-    }
-    if ((int)ha.size() < t.base + n) ha.resize(t.base + n);
-    ha[t.base + i] = info;
   }
   return t;
 }
@@ -278,7 +309,7 @@ struct rt_scene {
   Prim* d_prims = nullptr; double* d_mats = nullptr; double* d_lights = nullptr;
   int32_t* d_cut = nullptr;
   BvhNode* d_nodes = nullptr; float4* d_pbound = nullptr;   // culling hierarchy (large scenes only)
-  float* d_hnodes = nullptr; uint8_t* d_haxis = nullptr;    // heap-layout trees for nearest-hit walks
+  float* d_hpair = nullptr; uint8_t* d_haxis = nullptr; uint32_t* d_hleaf = nullptr;    // heap-layout tree for nearest-hit walks
   bool pool_trace = false;                                   // bounce levels through k_trace_pool (needs the heap trees)
   bool all_opaque = true;
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
@@ -362,7 +393,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   std::vector<int32_t> cut;        // <= 64 nodes covering both trees: entry points of the wave-level scan
   std::vector<BvhNode> nodes;
   std::vector<float4> pbound;
-  std::vector<float> hn; std::vector<uint8_t> ha; HeapTree heap[2];
+  HeapTree heap;
   {
     const char* e = getenv("RT_ACCEL");
     const bool want = !(e && e[0] == '0');
@@ -400,8 +431,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         cut.swap(next);
       }
       if (!(getenv("RT_BVH_HEAP") && atoi(getenv("RT_BVH_HEAP")) == 0)) {
-        heap[0] = build_heap(prims, 0, cnt[0], hn, ha);
-        heap[1] = build_heap(prims, cnt[0] + cnt[1], cnt[2], hn, ha);
+        heap = build_heap(prims, cnt[0], cnt[0] + cnt[1], cnt[2]);
       }
       pbound.resize(prims.size());
       for (size_t i = 0; i < prims.size(); ++i)
@@ -449,16 +479,20 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     HIPCHK_S(hipMalloc(&s->d_cut, 64 * sizeof(int32_t)));
     HIPCHK_S(hipMemcpy(s->d_cut, cut.data(), cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  if (!ha.empty()) {
-    HIPCHK_S(hipMalloc(&s->d_hnodes, hn.size() * sizeof(float)));
-    HIPCHK_S(hipMalloc(&s->d_haxis, ha.size()));
-    HIPCHK_S(hipMemcpy(s->d_hnodes, hn.data(), hn.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK_S(hipMemcpy(s->d_haxis, ha.data(), ha.size(), hipMemcpyHostToDevice));
+  if (heap.n_groups > 0) {
+    HIPCHK_S(hipMalloc(&s->d_hpair, heap.pair.size() * sizeof(float)));
+    HIPCHK_S(hipMalloc(&s->d_haxis, heap.axis.size()));
+    HIPCHK_S(hipMalloc(&s->d_hleaf, heap.leaf.size() * sizeof(uint32_t)));
+    HIPCHK_S(hipMemcpy(s->d_hpair, heap.pair.data(), heap.pair.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMemcpy(s->d_haxis, heap.axis.data(), heap.axis.size(), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMemcpy(s->d_hleaf, heap.leaf.data(), heap.leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
 #undef HIPCHK_S
-  s->pool_trace = s->d_hnodes != nullptr && !(getenv("RT_TRACE_POOL") && atoi(getenv("RT_TRACE_POOL")) == 0);
-  s->ds.ac.hnodes = s->d_hnodes; s->ds.ac.haxis = s->d_haxis; s->ds.ac.n_hnodes = (int)ha.size(); s->ds.ac.lds_hnodes = -1;
-  for (int k = 0; k < 2; ++k) { s->ds.ac.hL[k] = heap[k].L; s->ds.ac.hbase[k] = heap[k].base; s->ds.ac.hfirst[k] = heap[k].first; s->ds.ac.hcount[k] = heap[k].count; }
+  s->pool_trace = s->d_hpair != nullptr && !(getenv("RT_TRACE_POOL") && atoi(getenv("RT_TRACE_POOL")) == 0);
+  s->ds.ac.hpair = reinterpret_cast<const float4*>(s->d_hpair); s->ds.ac.haxis = s->d_haxis; s->ds.ac.hleaf = s->d_hleaf;
+  s->ds.ac.n_groups = heap.n_groups; s->ds.ac.n_sphere_groups = heap.n_sphere_groups; s->ds.ac.box_first = cnt[0] + cnt[1];
+  s->ds.ac.h_nS = cnt[0]; s->ds.ac.h_nB = cnt[2];
+  s->ds.ac.lds_hpair = s->ds.ac.lds_haxis = s->ds.ac.lds_hleaf = -1; s->ds.ac.n_lds_inner = 0;
   s->ds.ac.nodes = s->d_nodes; s->ds.ac.pbound = s->d_pbound; s->ds.ac.n_nodes = (int)nodes.size(); s->ds.ac.lds_nodes = -1;
   s->ds.ac.cut = s->d_cut; s->ds.ac.n_cut = (int)cut.size(); s->ds.ac.pad = 0;
   for (int k = 0; k < 3; ++k) { s->ds.ac.lo[k] = accel_lo[k]; s->ds.ac.hi[k] = accel_hi[k]; }
@@ -502,8 +536,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->d_lights) hipFree(s->d_lights);
   if (s->d_nodes) hipFree(s->d_nodes);
   if (s->d_pbound) hipFree(s->d_pbound);
-  if (s->d_hnodes) hipFree(s->d_hnodes);
+  if (s->d_hpair) hipFree(s->d_hpair);
   if (s->d_haxis) hipFree(s->d_haxis);
+  if (s->d_hleaf) hipFree(s->d_hleaf);
   if (s->d_cut) hipFree(s->d_cut);
   if (s->d_counters) hipFree(s->d_counters);
   for (Counters* h : s->h_slots) hipHostFree(h);
@@ -602,6 +637,10 @@ static int drain(rt_scene* s) {
       const double nw = (double)std::max(1ull, w[6]);
       fprintf(stderr, "[rt debug] per-lane heap walks since the last frame: %llu waves; per wave: %.1f node steps (lanes' mean %.1f), %.1f leaves (%.1f), "
               "%.1f exact tests (%.1f), %.0f cycles\n", w[6], w[0] / nw, w[1] / nw / 64, w[2] / nw, w[3] / nw / 64, w[4] / nw, w[5] / nw / 64, w[7] / nw);
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_pool_cyc), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pool_cyc), z, sizeof z);
+      if (w[5]) fprintf(stderr, "[rt debug] k_trace_pool wave cycles: refill %.3f, node steps %.3f, leaf bounds %.3f, exact tests %.3f, results %.3f of %llu; %llu rounds\n",
+                        (double)w[0] / w[5], (double)w[1] / w[5], (double)w[2] / w[5], (double)w[3] / w[5], (double)w[4] / w[5], w[5], w[6]);
     }
 #endif
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))

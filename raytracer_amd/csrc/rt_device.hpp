@@ -53,15 +53,16 @@ struct Accel {
   const int32_t* cut;      // <= 64 nodes that cover the tree (every leaf is one of them or below one): entry
   int32_t n_cut, pad;      // points of the wave-level scan (bvh_wave_leaves)
   float lo[3], hi[3];      // union of the root boxes
-  // Second view of the same record order for NEAREST-hit queries: per type one complete binary tree in heap layout
-  // (node i: children 2i+1, 2i+2; leaves at depth L own 8 consecutive records; padding nodes have empty boxes).
-  // A lane walks it front to back without a stack (heap_walk): nearer child first, so the first hit found is
-  // usually the nearest and the rest of the tree is cut off by it.
-  const float* hnodes;     // [n_hnodes][6] box lo xyz, hi xyz (rounded outward); nullptr: no heap trees
-  const uint8_t* haxis;    // [n_hnodes] inner nodes: bits 0-1 axis along which the children are ordered, bit 2: left child first for d[axis] > 0
-  int32_t n_hnodes;
-  int32_t lds_hnodes;      // device side: LDS byte address of a staged copy of hnodes followed by haxis, -1: none
-  int32_t hL[2], hbase[2], hfirst[2], hcount[2];   // [0] spheres, [1] boxes: depth, first node, first record, records
+  // Second hierarchy over the same records for NEAREST-hit queries: ONE complete binary tree (heap layout: children
+  // of i are 2i+1, 2i+2; n_groups leaves = the last n_groups indices) over the groups of <= 8 consecutive records of
+  // one type (sphere groups first, then box groups).  A lane walks it front to back without a stack (PoolRay).
+  // Inner node i stores the boxes of BOTH children (one step tests the pair), interleaved for packed math:
+  // hpair[3i..3i+2] = (L.lox, R.lox, L.loy, R.loy) (L.loz, R.loz, L.hix, R.hix) (L.hiy, R.hiy, L.hiz, R.hiz), rounded outward.
+  const float4* hpair;     // [max(n_groups - 1, 1)][3]; nullptr: no such tree
+  const uint8_t* haxis;    // [n_groups - 1] bits 0-1: axis along which the children are ordered, bit 2: left child first for d[axis] > 0
+  const uint32_t* hleaf;   // [n_groups] heap leaf -> group id
+  int32_t n_groups, n_sphere_groups, box_first, h_nS, h_nB;   // group g: records 8g.. (spheres) or box_first + 8(g - n_sphere_groups).. (boxes)
+  int32_t lds_hpair, lds_haxis, lds_hleaf, n_lds_inner;        // device side: LDS byte addresses of staged copies (-1: none), inner nodes staged
 };
 
 #ifdef __HIPCC__
@@ -385,77 +386,184 @@ __device__ __forceinline__ bool ray_may_touch(float cx, float cy, float cz, floa
   return (v2 <= r2) | ((tca >= 0.0f) & (d2 <= r2) & (tca - rs <= tmax_u));
 }
 
+typedef float rt_v2f __attribute__((ext_vector_type(2)));
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rt_v2f pk2_fma(rt_v2f a, rt_v2f b, rt_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ rt_v2f bc_lo(rt_v2f a) { return __builtin_shufflevector(a, a, 0, 0); }   // -> op_sel broadcast of v_pk_fma_f32
+__device__ __forceinline__ rt_v2f bc_hi(rt_v2f a) { return __builtin_shufflevector(a, a, 1, 1); }
+
 #ifdef RT_DEBUG_KERNEL
 // audit build: k_trace walk statistics (waves, wave-level / per-lane node steps, leaves, exact tests, cycles)
 __device__ unsigned long long g_walk_dbg[8];
+__device__ unsigned long long g_pool_cyc[8];     // k_trace_pool wave cycles: refill, node steps, leaf bounds, exact tests, results, all, rounds
 __device__ __forceinline__ bool wave_first_active() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
+#ifdef RT_NO_WALK_COUNT     // (cycle profiles: the counting atomics would dominate)
+#define RT_WALK_COUNT(i) do { } while (0)
+#else
 #define RT_WALK_COUNT(i) do { atomicAdd(&g_walk_dbg[(i) + 1], 1ull); if (wave_first_active()) atomicAdd(&g_walk_dbg[i], 1ull); } while (0)
+#endif
 #else
 #define RT_WALK_COUNT(i) do { } while (0)
 #endif
 
-// Front-to-back walk of the heap-layout trees (spheres, then boxes) by one lane, stackless: `trail` holds one bit per
-// level of the current path (LSB = current node), set while the node's sibling is still to be visited.  The nearer
-// child (by the sign of the ray direction along the axis the children are ordered on) is entered first.
-// slab(lo, hi) is the query's conservative box test (it sees the current best distance), leaf(first_record, count)
-// processes a leaf.  Two nested loops: the inner one steps through nodes until the lane holds a leaf that passed the
-// slab test (or has finished); only then, with every lane of the wave in that state, the leaf code runs — once per
-// round for all lanes instead of once per node step in which any lane happens to reach a leaf (measured on the
-// synthetic 4608-object scene: 23 leaf rounds per wave before, against 4 leaves per lane).
-template <class Slab, class Leaf>
-__device__ __forceinline__ void heap_walk(const Accel& ac, float ux, float uy, float uz, Slab slab, Leaf leaf) {
-  int tree = ac.hcount[0] > 0 ? 0 : 1;
-  if (ac.hcount[tree] <= 0) return;
-  int base = ac.hbase[tree], first_leaf = (1 << ac.hL[tree]) - 1;
-  int idx = 0;
-  uint32_t trail = 0u;
-  bool done = false;
-  for (;;) {
-    int leaf_j = -1, leaf_tree = 0;
-    while (!done) {
-      RT_WALK_COUNT(0);
-      float lo[3], hi[3];
-      uint32_t ax;
-      if (ac.lds_hnodes >= 0) {
-        typedef float rt_v2f __attribute__((ext_vector_type(2)));
-        const __attribute__((address_space(3))) rt_v2f* q =
-            (const __attribute__((address_space(3))) rt_v2f*)(uintptr_t)(uint32_t)ac.lds_hnodes + 3 * (base + idx);
-        const rt_v2f a = q[0], b = q[1], c = q[2];
-        lo[0] = a.x; lo[1] = a.y; lo[2] = b.x; hi[0] = b.y; hi[1] = c.x; hi[2] = c.y;
-        const __attribute__((address_space(3))) uint8_t* qa =
-            (const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(uint32_t)(ac.lds_hnodes + 24 * ac.n_hnodes);
-        ax = qa[base + idx];
-      } else {
-        const float* q = ac.hnodes + 6 * (size_t)(base + idx);
-        lo[0] = q[0]; lo[1] = q[1]; lo[2] = q[2]; hi[0] = q[3]; hi[1] = q[4]; hi[2] = q[5];
-        ax = ac.haxis[base + idx];
-      }
-      const bool hit = slab(lo, hi);
-      if (hit && idx < first_leaf) {                      // inner node: enter the nearer child, the other one stays pending
-        const float da = (ax & 3u) == 0u ? ux : ((ax & 3u) == 1u ? uy : uz);
-        const bool left_first = ((ax >> 2) & 1u) ? (da > 0.0f) : !(da > 0.0f);
-        idx = 2 * idx + (left_first ? 1 : 2);
-        trail = (trail << 1) | 1u;
-        continue;
-      }
-      if (hit) { leaf_j = idx - first_leaf; leaf_tree = tree; }
-      // move on to the next node to visit (before the leaf is processed: it has no children)
-      if (trail != 0u) {
-        const int k = __ffs((int)trail) - 1;              // levels to climb to the nearest node with a pending sibling
-        idx = ((idx + 1) >> k) - 1;
-        trail = (trail >> k) ^ 1u;
-        idx = (idx & 1) ? idx + 1 : idx - 1;              // its sibling
-      } else if (tree == 0 && ac.hcount[1] > 0) {         // spheres finished: the box tree
-        tree = 1; base = ac.hbase[1]; first_leaf = (1 << ac.hL[1]) - 1; idx = 0;
-      } else {
-        done = true;
-      }
-      if (leaf_j >= 0) break;
+// One ray's nearest-hit query over the heap-layout tree (Accel::hpair) as a state that can be suspended and resumed
+// (k_trace_pool: lanes whose walk has ended take the next ray while the others carry on).  begin() is nearest_accel's
+// set-up (planes, walk origin, conservative fp32 tests) and exact() its on_prim: the result is the same (t, record).
+//
+// The walk is stackless and front to back.  `idx` is the current node, `trail` holds one bit per level of the path
+// (LSB = current node), set while the node's sibling is still to be visited.  One step at an inner node tests the boxes
+// of both children (they see the current best distance) and enters the nearer one that passed — by the sign of the ray
+// direction along the axis the children are ordered on —, leaving the other pending if it passed too; with none, or
+// at a leaf that has been processed, it climbs to the nearest ancestor with a pending sibling and goes there.  A node
+// reached by climbing is not tested again: its children are (their boxes lie inside it).
+struct PoolRay {
+  d3 o, d;
+  double best, t0;
+  int bk, borig;
+  float ofx, ofy, ofz, ux, uy, uz, len, tmax_u;
+  rt_v2f p0, p1, p2, p3, p4;   // (ix, clx) (iy, cly) (iz, clz) (chx, chy) (chz, -): slab test t(lo) = lo*i + cl, t(hi) = hi*i + ch
+  int idx;
+  uint32_t trail;
+  bool fresh, done;
+
+  __device__ __forceinline__ void begin(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o_, d3 d_, double plane_thr) {
+    o = o_; d = d_;
+    best = RT_INF; bk = -1; borig = 0x7fffffff;
+    for (int k = nS, e = nS + nP; k < e; ++k) {
+      const double t = plane_t(P[k], o, d, plane_thr);
+      const int og = P[k].orig;
+      if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
     }
-    if (leaf_j < 0) break;
-    const int nj = min(8, ac.hcount[leaf_tree] - 8 * leaf_j);
-    if (nj > 0) leaf(ac.hfirst[leaf_tree] + 8 * leaf_j, nj);
+    t0 = 0.0;
+    bool skip_tree = false;
+    {   // far origins: walk from where the ray enters the hierarchy's bounds (see nearest_accel)
+      const double far_ = fabs(o.x) + fabs(o.y) + fabs(o.z);
+      const double ext = (double)(ac.hi[0] - ac.lo[0]) + (double)(ac.hi[1] - ac.lo[1]) + (double)(ac.hi[2] - ac.lo[2]);
+      const bool outside = (o.x < ac.lo[0]) | (o.x > ac.hi[0]) | (o.y < ac.lo[1]) | (o.y > ac.hi[1]) | (o.z < ac.lo[2]) | (o.z > ac.hi[2]);
+      if (outside & (far_ > 4.0 * ext + 16.0)) {
+        double tn = 0.0, tf = RT_INF;
+        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+        const double mg = 1e-3 * (ext + 1.0);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          if (fabs(dd[ax]) > 1e-300) {
+            const double a_ = ((double)ac.lo[ax] - mg - oo[ax]) / dd[ax], b_ = ((double)ac.hi[ax] + mg - oo[ax]) / dd[ax];
+            tn = fmax(tn, fmin(a_, b_)); tf = fmin(tf, fmax(a_, b_));
+          } else if (oo[ax] < (double)ac.lo[ax] - mg || oo[ax] > (double)ac.hi[ax] + mg) tf = -1.0;
+        }
+        if (!(tn <= tf)) skip_tree = true;
+        else t0 = tn;
+      }
+    }
+    ofx = (float)(o.x + t0 * d.x); ofy = (float)(o.y + t0 * d.y); ofz = (float)(o.z + t0 * d.z);
+    ux = (float)d.x; uy = (float)d.y; uz = (float)d.z;
+    const float len2 = fmaf(uz, uz, fmaf(uy, uy, ux * ux));
+    const float inv = 1.0f / sqrtf(len2);
+    len = len2 * inv;
+    ux *= inv; uy *= inv; uz *= inv;
+    tmax_u = best < 1e30 ? (float)((best - t0) * len) * 1.00001f + 1e-5f : 3.0e38f;
+    if (skip_tree) tmax_u = -1.0f;       // every box / record test fails
+    const float ix = fabsf(ux) > 1e-20f ? 1.0f / ux : 1e30f, iy = fabsf(uy) > 1e-20f ? 1.0f / uy : 1e30f,
+                iz = fabsf(uz) > 1e-20f ? 1.0f / uz : 1e30f;
+    // nearest_accel's slab test, (lo - dl - of) * i, as one fma per plane: the rounding of the constants is
+    // 1.2e-7 |of + dl| |i|, far inside the dl |i| the inflation gives; the fma's own rounding is relative to t and
+    // covered by the 1.00001 of the comparison.  (An overflow to NaN drops that axis: v_min/v_max return the other operand.)
+    const float dl = 4e-5f * (1.0f + fabsf(ofx) + fabsf(ofy) + fabsf(ofz));
+    p0.x = ix; p0.y = (-ofx - dl) * ix; p3.x = (-ofx + dl) * ix;
+    p1.x = iy; p1.y = (-ofy - dl) * iy; p3.y = (-ofy + dl) * iy;
+    p2.x = iz; p2.y = (-ofz - dl) * iz; p4.x = (-ofz + dl) * iz; p4.y = 0.0f;
+    idx = 0; trail = 0u; fresh = true; done = false;
   }
+  __device__ __forceinline__ bool may(const float4& b) const { return ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u); }
+  __device__ __forceinline__ void exact(const Prim* __restrict__ P, int nS, int k) {
+    const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
+    const int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) {
+      best = t; bk = k; borig = og;
+      tmax_u = (float)((best - t0) * len) * 1.00001f + 1e-5f;
+    }
+  }
+  // Steps until this lane has arrived at a leaf (returns the heap index of the leaf), has finished (returns -1,
+  // done), or — the walk can be resumed — fewer than `min_lanes` lanes of the wave are still stepping (returns -1).
+  __device__ __forceinline__ int to_next_leaf(const Accel& ac, int min_lanes) {
+    const int n_inner = ac.n_groups - 1;
+    if (fresh) { fresh = false; if (n_inner == 0) return 0; }      // a single group: the root is the leaf
+    int leaf = -1;
+    const uint32_t sgn = (ux > 0.0f ? 1u : 0u) | (uy > 0.0f ? 2u : 0u) | (uz > 0.0f ? 4u : 0u);
+    const int min_eff = min(min_lanes, __popcll(__ballot(1)) >> 2);        // (a quarter of the lanes that entered at most)
+    while (!done && leaf < 0) {
+      if (__popcll(__ballot(1)) < min_eff) break;
+      RT_WALK_COUNT(0);
+      asm("" : "+v"(p0)); asm("" : "+v"(p1)); asm("" : "+v"(p2)); asm("" : "+v"(p3)); asm("" : "+v"(p4));   // keeps the pairs pairs: op_sel broadcasts
+      const bool inner = idx < n_inner;
+      const int ii = inner ? idx : 0;
+      rt_v4f A, B, C;
+      uint32_t ax;
+      if (ii < ac.n_lds_inner) {
+        const __attribute__((address_space(3))) rt_v4f* q = (const __attribute__((address_space(3))) rt_v4f*)(uintptr_t)(uint32_t)ac.lds_hpair + 3 * ii;
+        A = q[0]; B = q[1]; C = q[2];
+        ax = ((const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(uint32_t)ac.lds_haxis)[ii];
+      } else {
+        const rt_v4f* q = reinterpret_cast<const rt_v4f*>(ac.hpair) + 3 * (size_t)ii;
+        A = q[0]; B = q[1]; C = q[2];
+        ax = ac.haxis[n_inner > 0 ? ii : 0];
+      }
+      rt_v2f v;
+      v.x = A.x; v.y = A.y; const rt_v2f tlx = pk2_fma(v, bc_lo(p0), bc_hi(p0));
+      v.x = A.z; v.y = A.w; const rt_v2f tly = pk2_fma(v, bc_lo(p1), bc_hi(p1));
+      v.x = B.x; v.y = B.y; const rt_v2f tlz = pk2_fma(v, bc_lo(p2), bc_hi(p2));
+      v.x = B.z; v.y = B.w; const rt_v2f thx = pk2_fma(v, bc_lo(p0), bc_lo(p3));
+      v.x = C.x; v.y = C.y; const rt_v2f thy = pk2_fma(v, bc_lo(p1), bc_hi(p3));
+      v.x = C.z; v.y = C.w; const rt_v2f thz = pk2_fma(v, bc_lo(p2), bc_lo(p4));
+      const float tnL = fmaxf(fmaxf(fminf(tlx.x, thx.x), fminf(tly.x, thy.x)), fmaxf(fminf(tlz.x, thz.x), 0.0f));
+      const float tfL = fminf(fminf(fmaxf(tlx.x, thx.x), fmaxf(tly.x, thy.x)), fminf(fmaxf(tlz.x, thz.x), tmax_u));
+      const float tnR = fmaxf(fmaxf(fminf(tlx.y, thx.y), fminf(tly.y, thy.y)), fmaxf(fminf(tlz.y, thz.y), 0.0f));
+      const float tfR = fminf(fminf(fmaxf(tlx.y, thx.y), fmaxf(tly.y, thy.y)), fminf(fmaxf(tlz.y, thz.y), tmax_u));
+      const bool hL = inner & (tnL <= fmaf(tfL, 1.00001f, 1e-5f));
+      const bool hR = inner & (tnR <= fmaf(tfR, 1.00001f, 1e-5f));
+      const uint32_t left_first = ((sgn >> (ax & 3u)) ^ (ax >> 2) ^ 1u) & 1u;      // bit 2 of ax: left child first for d[axis] > 0
+      const bool hn = left_first ? hL : hR, hf = left_first ? hR : hL;             // nearer / farther child
+      const int near = 2 * idx + 2 - (int)left_first, far = 2 * idx + 1 + (int)left_first;
+      const bool any = hn | hf;
+      const int idx_d = hn ? near : far;
+      const uint32_t trail_d = (trail << 1) | ((hn & hf) ? 1u : 0u);
+      const int k = __ffs((int)trail) - 1;                                        // levels to climb to the nearest node with a pending sibling
+      int idx_p = ((idx + 1) >> (k & 31)) - 1;
+      idx_p = ((idx_p - 1) ^ 1) + 1;                                              // its sibling
+      const uint32_t trail_p = (trail >> (k & 31)) ^ 1u;
+      done = !any & (trail == 0u);
+      idx = any ? idx_d : idx_p;
+      trail = any ? trail_d : trail_p;
+      leaf = (!done && idx >= n_inner) ? idx : -1;
+    }
+    return leaf;
+  }
+  // Records of a heap leaf: first record, *nj = their number (<= 8).
+  __device__ __forceinline__ static int leaf_records(const Accel& ac, int leaf, int* nj) {
+    const int li = leaf - (ac.n_groups - 1);
+    const uint32_t g = ac.lds_hleaf >= 0 ? ((const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(uint32_t)ac.lds_hleaf)[li] : ac.hleaf[li];
+    const bool sph = (int)g < ac.n_sphere_groups;
+    const int j = sph ? (int)g : (int)g - ac.n_sphere_groups;
+    *nj = min(8, (sph ? ac.h_nS : ac.h_nB) - 8 * j);
+    return (sph ? 0 : ac.box_first) + 8 * j;
+  }
+};
+
+// nearest() for one lane over the heap-layout tree.
+__device__ __forceinline__ double nearest_heap(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d, int* k_out, double plane_thr) {
+  PoolRay pr;
+  pr.begin(P, nS, nP, ac, o, d, plane_thr);
+  for (;;) {
+    const int leaf = pr.to_next_leaf(ac, 1);
+    if (leaf < 0) break;
+    int nj;
+    const int rec = PoolRay::leaf_records(ac, leaf, &nj);
+    BvhNode nd; nd.first = rec; nd.skip_count = (uint32_t)nj << 28;
+    bvh_leaf(ac, nd, [&](const float4& b) __attribute__((always_inline)) { return pr.may(b); },
+             [&](int k) __attribute__((always_inline)) { pr.exact(P, nS, k); });
+  }
+  *k_out = pr.bk;
+  return pr.best;
 }
 
 // nearest() through the hierarchy: identical result (same exact tests, same (t, orig) rule), the
@@ -471,6 +579,7 @@ constexpr int WAVE_LEAF_CAP = 64;     // leaves a per-wave list holds
 template <bool WAVE>
 __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o, d3 d,
                                                 int* k_out, double plane_thr, int* wave_list, bool try_wave) {
+  if (!WAVE && ac.hpair != nullptr) return nearest_heap(P, nS, nP, ac, o, d, k_out, plane_thr);
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   for (int k = nS, e = nS + nP; k < e; ++k) {
     double t = plane_t(P[k], o, d, plane_thr);
@@ -589,167 +698,14 @@ __device__ __forceinline__ double nearest_accel(const Prim* __restrict__ P, int 
       const BvhNode nd = load_node(ac, wave_list[e]);
       if (node_hit(nd)) bvh_leaf(ac, nd, prim_may, on_prim);
     }
-  } else if (ac.hnodes != nullptr) {
-    // per-lane front-to-back walks of the two heap trees (spheres, boxes): the nearest hit is found early and the
-    // remaining nodes fail the slab test against it
-    auto slab = [&](const float (&lo)[3], const float (&hi)[3]) __attribute__((always_inline)) {
-      const float ax = (lo[0] - dl - ofx) * ix, bx = (hi[0] + dl - ofx) * ix;
-      const float ay = (lo[1] - dl - ofy) * iy, by = (hi[1] + dl - ofy) * iy;
-      const float az = (lo[2] - dl - ofz) * iz, bz = (hi[2] + dl - ofz) * iz;
-      const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-      const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_u));
-      return tn <= tf * 1.00001f + 1e-5f;
-    };
-    auto leaf = [&](int first, int nj) __attribute__((always_inline)) {
-      RT_WALK_COUNT(2);
-      BvhNode nd; nd.first = first; nd.skip_count = (uint32_t)nj << 28;
-      bvh_leaf(ac, nd, prim_may, on_prim);
-    };
-#ifdef RT_DEBUG_KERNEL
-    const long long ck0_ = clock64();
-#endif
-    heap_walk(ac, ux, uy, uz, slab, leaf);
-#ifdef RT_DEBUG_KERNEL
-    if (__lane_id() == 0) { atomicAdd(&g_walk_dbg[6], 1ull); atomicAdd(&g_walk_dbg[7], (unsigned long long)(clock64() - ck0_)); }
-#endif
+  } else if (ac.hpair != nullptr && ac.lds_nodes < 0) {       // (k_trace level 0 has the skip-link nodes in LDS: its scattered waves walk those)
+    return nearest_heap(P, nS, nP, ac, o, d, k_out, plane_thr);
   } else {
     bvh_walk(ac, node_hit, prim_may, on_prim);
   }
   *k_out = bk;
   return best;
 }
-
-// One ray's nearest-hit query over the heap trees as a state that can be suspended and resumed (k_trace_pool: lanes
-// whose walk has ended take the next ray while the others carry on).  begin() is nearest_accel's set-up (planes, walk
-// origin, conservative fp32 tests) and exact() its on_prim: the result is the same (t, record) pair.
-struct PoolRay {
-  d3 o, d;
-  double best, t0;
-  int bk, borig;
-  float ofx, ofy, ofz, ux, uy, uz, ix, iy, iz, len, tmax_u;
-  float clx, cly, clz, chx, chy, chz;      // slab test: t(lo) = lo*i + cl, t(hi) = hi*i + ch (boxes inflated by dl)
-  int idx, tree;            // tree: 0 spheres, 1 boxes, 2 finished
-  uint32_t trail;
-
-  __device__ __forceinline__ void begin(const Prim* __restrict__ P, int nS, int nP, const Accel& ac, d3 o_, d3 d_, double plane_thr) {
-    o = o_; d = d_;
-    best = RT_INF; bk = -1; borig = 0x7fffffff;
-    for (int k = nS, e = nS + nP; k < e; ++k) {
-      const double t = plane_t(P[k], o, d, plane_thr);
-      const int og = P[k].orig;
-      if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
-    }
-    t0 = 0.0;
-    bool skip_tree = false;
-    {   // far origins: walk from where the ray enters the hierarchy's bounds (see nearest_accel)
-      const double far_ = fabs(o.x) + fabs(o.y) + fabs(o.z);
-      const double ext = (double)(ac.hi[0] - ac.lo[0]) + (double)(ac.hi[1] - ac.lo[1]) + (double)(ac.hi[2] - ac.lo[2]);
-      const bool outside = (o.x < ac.lo[0]) | (o.x > ac.hi[0]) | (o.y < ac.lo[1]) | (o.y > ac.hi[1]) | (o.z < ac.lo[2]) | (o.z > ac.hi[2]);
-      if (outside & (far_ > 4.0 * ext + 16.0)) {
-        double tn = 0.0, tf = RT_INF;
-        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-        const double mg = 1e-3 * (ext + 1.0);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          if (fabs(dd[ax]) > 1e-300) {
-            const double a_ = ((double)ac.lo[ax] - mg - oo[ax]) / dd[ax], b_ = ((double)ac.hi[ax] + mg - oo[ax]) / dd[ax];
-            tn = fmax(tn, fmin(a_, b_)); tf = fmin(tf, fmax(a_, b_));
-          } else if (oo[ax] < (double)ac.lo[ax] - mg || oo[ax] > (double)ac.hi[ax] + mg) tf = -1.0;
-        }
-        if (!(tn <= tf)) skip_tree = true;
-        else t0 = tn;
-      }
-    }
-    ofx = (float)(o.x + t0 * d.x); ofy = (float)(o.y + t0 * d.y); ofz = (float)(o.z + t0 * d.z);
-    ux = (float)d.x; uy = (float)d.y; uz = (float)d.z;
-    const float len2 = fmaf(uz, uz, fmaf(uy, uy, ux * ux));
-    const float inv = 1.0f / sqrtf(len2);
-    len = len2 * inv;
-    ux *= inv; uy *= inv; uz *= inv;
-    tmax_u = best < 1e30 ? (float)((best - t0) * len) * 1.00001f + 1e-5f : 3.0e38f;
-    if (skip_tree) tmax_u = -1.0f;
-    ix = fabsf(ux) > 1e-20f ? 1.0f / ux : 1e30f; iy = fabsf(uy) > 1e-20f ? 1.0f / uy : 1e30f; iz = fabsf(uz) > 1e-20f ? 1.0f / uz : 1e30f;
-    // nearest_accel's slab test, (lo - dl - of) * i, as one fma per plane: the rounding of the constants is
-    // 1.2e-7 |of + dl| |i|, far inside the dl |i| the inflation gives; the fma's own rounding is relative to t and
-    // covered by the 1.00001 of the comparison.  (An overflow to NaN drops that axis: v_min/v_max return the other operand.)
-    const float dl = 4e-5f * (1.0f + fabsf(ofx) + fabsf(ofy) + fabsf(ofz));
-    clx = (-ofx - dl) * ix; chx = (-ofx + dl) * ix;
-    cly = (-ofy - dl) * iy; chy = (-ofy + dl) * iy;
-    clz = (-ofz - dl) * iz; chz = (-ofz + dl) * iz;
-    idx = 0; trail = 0u;
-    tree = ac.hcount[0] > 0 ? 0 : (ac.hcount[1] > 0 ? 1 : 2);
-  }
-  __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz) const {
-    const float ax = fmaf(lx, ix, clx), bx = fmaf(hx, ix, chx);
-    const float ay = fmaf(ly, iy, cly), by = fmaf(hy, iy, chy);
-    const float az = fmaf(lz, iz, clz), bz = fmaf(hz, iz, chz);
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax_u));
-    return tn <= fmaf(tf, 1.00001f, 1e-5f);
-  }
-  __device__ __forceinline__ bool may(const float4& b) const { return ray_may_touch(b.x, b.y, b.z, b.w, ofx, ofy, ofz, ux, uy, uz, tmax_u); }
-  __device__ __forceinline__ void exact(const Prim* __restrict__ P, int nS, int k) {
-    const double t = (k < nS) ? sphere_t(P[k], o, d) : box_hit<false>(P[k], o, d, nullptr);
-    const int og = P[k].orig;
-    if (t < best || (t == best && og < borig && bk >= 0)) {
-      best = t; bk = k; borig = og;
-      tmax_u = (float)((best - t0) * len) * 1.00001f + 1e-5f;
-    }
-  }
-  // Node steps until this lane holds a leaf that passed the slab test (returns its first record, *nj = its records)
-  // or has finished both trees (returns -1, tree == 2), or — the walk can be resumed — fewer than `min_lanes` lanes of
-  // the wave are still stepping (returns -1, tree < 2).  Front to back, stackless (see heap_walk).
-  __device__ __forceinline__ int to_next_leaf(const Accel& ac, int* nj, int min_lanes) {
-    int lidx = -1, ltree = 0;
-    const int fl0 = (1 << ac.hL[0]) - 1, fl1 = (1 << ac.hL[1]) - 1;
-    const uint32_t sgn = (ux > 0.0f ? 1u : 0u) | (uy > 0.0f ? 2u : 0u) | (uz > 0.0f ? 4u : 0u);
-    const int min_eff = min(min_lanes, __popcll(__ballot(1)) >> 2);        // (a quarter of the lanes that entered at most)
-    while (tree < 2 && lidx < 0) {
-      if (__popcll(__ballot(1)) < min_eff) break;
-      RT_WALK_COUNT(0);
-      const int base = tree ? ac.hbase[1] : ac.hbase[0];
-      const int first_leaf = tree ? fl1 : fl0;
-      float lx, ly, lz, hx, hy, hz;
-      uint32_t ax;
-      if (ac.lds_hnodes >= 0) {
-        typedef float rt_v2f __attribute__((ext_vector_type(2)));
-        const __attribute__((address_space(3))) rt_v2f* q =
-            (const __attribute__((address_space(3))) rt_v2f*)(uintptr_t)(uint32_t)ac.lds_hnodes + 3 * (base + idx);
-        const rt_v2f a = q[0], b = q[1], c = q[2];
-        lx = a.x; ly = a.y; lz = b.x; hx = b.y; hy = c.x; hz = c.y;
-        const __attribute__((address_space(3))) uint8_t* qa =
-            (const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(uint32_t)(ac.lds_hnodes + 24 * ac.n_hnodes);
-        ax = qa[base + idx];
-      } else {
-        const float* q = ac.hnodes + 6 * (size_t)(base + idx);
-        lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
-        ax = ac.haxis[base + idx];
-      }
-      const bool hit = slab(lx, ly, lz, hx, hy, hz);
-      const bool inner = idx < first_leaf;
-      const bool desc = hit & inner;
-      lidx = (hit & !inner) ? idx : lidx;
-      ltree = tree;
-      // both successors, then a select: the nearer child (inner node that was hit), or the next pending sibling
-      const uint32_t left_first = ((sgn >> (ax & 3u)) ^ (ax >> 2) ^ 1u) & 1u;      // bit 2 of ax: left child first for d[axis] > 0
-      const int idx_d = 2 * idx + 2 - (int)left_first;
-      const bool empty = trail == 0u;
-      const int k = __ffs((int)trail) - 1;
-      int idx_p = ((idx + 1) >> (k & 31)) - 1;
-      idx_p = ((idx_p - 1) ^ 1) + 1;                                              // sibling
-      const uint32_t trail_p = (trail >> (k & 31)) ^ 1u;
-      const bool fin = !desc & empty;                                             // this tree is done
-      idx = desc ? idx_d : (fin ? 0 : idx_p);
-      trail = desc ? ((trail << 1) | 1u) : (fin ? 0u : trail_p);
-      tree = fin ? ((tree == 0 && ac.hcount[1] > 0) ? 1 : 2) : tree;
-    }
-    if (lidx < 0) return -1;
-    const int j = lidx - (ltree ? fl1 : fl0);
-    const int n = min(8, (ltree ? ac.hcount[1] : ac.hcount[0]) - 8 * j);
-    *nj = n;
-    return n > 0 ? (ltree ? ac.hfirst[1] : ac.hfirst[0]) + 8 * j : -2;            // -2: a padding leaf (cannot pass the slab test)
-  }
-};
 
 __device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
   if (p.type == 0) return sphere_normal(p, o, d, t);

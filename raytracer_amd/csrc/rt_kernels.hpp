@@ -122,21 +122,10 @@ __device__ __forceinline__ const Prim* stage_scene(const DevScene& sc, Prim* lds
 // dependent loads, LDS latency is several times shorter than L2's.
 constexpr int LDS_NODES = 980;      // (k_trace's nodes + hit staging + wave lists then fit four workgroups per CU)
 template <bool LDS_SCENE>
-__device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds, bool heap = false) {
+__device__ __forceinline__ Accel stage_accel(const DevScene& sc, BvhNode* lds) {
   Accel a = sc.ac;
-  a.lds_nodes = -1; a.lds_hnodes = -1;
-  if (LDS_SCENE) { a.n_nodes = 0; a.hnodes = nullptr; return a; }
-  if (heap && a.hnodes != nullptr && (size_t)a.n_hnodes * 25 <= (size_t)LDS_NODES * sizeof(BvhNode)) {
-    // the heap trees instead of the skip-link nodes (per-lane nearest-hit walks: k_trace below level 0)
-    const int words = a.n_hnodes * 6;
-    float* dst = reinterpret_cast<float*>(lds);
-    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = a.hnodes[i];
-    uint8_t* dsta = reinterpret_cast<uint8_t*>(lds) + 24 * a.n_hnodes;
-    for (int i = threadIdx.x; i < a.n_hnodes; i += blockDim.x) dsta[i] = a.haxis[i];
-    __syncthreads();
-    a.lds_hnodes = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) BvhNode*)lds;
-    return a;
-  }
+  a.lds_nodes = -1; a.lds_hpair = a.lds_haxis = a.lds_hleaf = -1; a.n_lds_inner = 0;
+  if (LDS_SCENE) { a.n_nodes = 0; a.hpair = nullptr; return a; }
   if (a.n_nodes <= 0 || a.n_nodes > LDS_NODES) return a;
   const int words = a.n_nodes * (int)(sizeof(BvhNode) / 16);
   const uint4* src = reinterpret_cast<const uint4*>(a.nodes);
@@ -235,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
   __shared__ uint32_t s_count, s_base;
   __shared__ int s_wleaves[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_LEAF_CAP];      // per-wave leaf lists (nearest_accel<true>)
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
-  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes, level > 0 || (fp.debug & 4096u));
+  const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   // wave-level scan for the camera rays only (8x8 pixel tiles: one origin, a thin cone; measured 1.13 -> 0.74 ms on
   // the synthetic 4K frame).  The deeper levels' waves mix transmitted and reflected rays of many surfaces: their
   // cones are too wide, and the attempt costs them ~3 %.  RT_DEBUG_STATS=4096: per-lane walks everywhere (A/B).
@@ -355,11 +344,33 @@ constexpr int POOL_MIN_STEP = RT_POOL_MIN_STEP; // node steps stop when fewer la
 template <typename FB>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_trace_pool(DevScene sc, FrameParams fp, int level, RayQueue q,
                                                  HitRec* __restrict__ hits, Counters* C, FB* __restrict__ fb) {
-  __shared__ BvhNode s_nodes[LDS_NODES];
+  constexpr int TREE_BYTES = LDS_NODES * (int)sizeof(BvhNode);
+  __shared__ __attribute__((aligned(16))) unsigned char s_tree[TREE_BYTES];     // child-box pairs | leaf table | axis bytes
   __shared__ HitRec s_whits[BLOCK / 64][128];
   __shared__ uint32_t s_segfirst[NSEG + 1];
   const Prim* P = sc.prims;
-  const Accel ac = stage_accel<false>(sc, s_nodes, true);
+  Accel ac = sc.ac;
+  ac.lds_nodes = -1; ac.lds_hleaf = -1;
+  {
+    // everything when it fits (53 bytes per group), else the top of the tree (heap order is level order) and the
+    // leaf table stays in global memory
+    const int n_inner = ac.n_groups - 1;
+    const bool all = 48 * max(n_inner, 1) + 4 * ac.n_groups + n_inner <= TREE_BYTES;
+    const int n_lp = all ? n_inner : min(n_inner, TREE_BYTES / 49);
+    float4* dp = reinterpret_cast<float4*>(s_tree);
+    for (int i = threadIdx.x; i < 3 * n_lp; i += BLOCK) dp[i] = ac.hpair[i];
+    int off = 48 * max(n_lp, 1);
+    if (all) {
+      uint32_t* dl_ = reinterpret_cast<uint32_t*>(s_tree + off);
+      for (int i = threadIdx.x; i < ac.n_groups; i += BLOCK) dl_[i] = ac.hleaf[i];
+      ac.lds_hleaf = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(s_tree + off);
+      off += 4 * ac.n_groups;
+    }
+    for (int i = threadIdx.x; i < n_lp; i += BLOCK) s_tree[off + i] = ac.haxis[i];
+    ac.lds_hpair = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_tree;
+    ac.lds_haxis = (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(s_tree + off);
+    ac.n_lds_inner = n_lp;
+  }
   const uint32_t seg_cap = fp.queue_cap / NSEG;
   if (threadIdx.x < 64) {                          // lane q: segment q; inclusive scans over the wave (as in k_trace)
     const uint32_t raw = C->segcnt[level & 1][threadIdx.x * 32];
@@ -388,8 +399,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
   uint32_t pool_next = 0, pool_end = 0;            // slots of the current pool not handed out yet (wave-uniform)
   bool exhausted = false;                          // no more chunks (wave-uniform)
   bool busy = false;                               // this lane holds a ray
-  PoolRay pr; pr.tree = 2; pr.idx = 0; pr.trail = 0u; pr.bk = -1; pr.best = RT_INF;
+  PoolRay pr; pr.done = true; pr.fresh = false; pr.idx = 0; pr.trail = 0u; pr.bk = -1; pr.best = RT_INF;
   uint32_t slot = 0;
+#ifdef RT_DEBUG_KERNEL
+  long long ck[7] = {0, 0, 0, 0, 0, 0, 0}; const long long ck_begin = clock64(); long long ck_t = ck_begin;
+#define RT_POOL_TICK(i) do { const long long n_ = clock64(); ck[i] += n_ - ck_t; ck_t = n_; } while (0)
+#else
+#define RT_POOL_TICK(i) do { } while (0)
+#endif
   for (;;) {
     // ---- refill: idle lanes take the next rays of the pool
     const unsigned long long idle = __ballot(!busy);
@@ -425,13 +442,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
       }
     }
     if (__ballot(busy) == 0ull) break;             // every ray of every chunk this wave took is done
+    RT_POOL_TICK(0);
     // ---- node steps until every busy lane holds a leaf or has finished, then the leaves together
     int nj = 0;
     int rec = -1;
-    if (busy) rec = pr.to_next_leaf(ac, &nj, POOL_MIN_STEP);
+    if (busy) {
+      const int leaf = pr.to_next_leaf(ac, POOL_MIN_STEP);
+      if (leaf >= 0) rec = PoolRay::leaf_records(ac, leaf, &nj);
+    }
+    RT_POOL_TICK(1);
+    uint32_t cand = 0;
     if (rec >= 0) {
       RT_WALK_COUNT(2);
-      uint32_t cand = 0;
 #pragma unroll
       for (int h = 0; h < 8; h += 4) {
         if (h > 0 && nj <= h) break;
@@ -441,15 +463,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #pragma unroll
         for (int j = 0; j < 4; ++j) cand |= (h + j < nj && pr.may(b[j])) ? (1u << (h + j)) : 0u;
       }
-      while (cand) {
-        RT_WALK_COUNT(4);
-        const int j = __ffs((int)cand) - 1;
-        cand &= cand - 1;
-        pr.exact(P, sc.nS, rec + j);
-      }
     }
+    RT_POOL_TICK(2);
+    while (cand) {
+      RT_WALK_COUNT(4);
+      const int j = __ffs((int)cand) - 1;
+      cand &= cand - 1;
+      pr.exact(P, sc.nS, rec + j);
+    }
+    RT_POOL_TICK(3);
     // ---- finished walks: miss -> background, hit -> the wave's buffer
-    const bool fin = busy && rec == -1 && pr.tree == 2;
+    const bool fin = busy && rec < 0 && pr.done;
     const bool hit = fin && pr.bk >= 0;
     if (fin && !hit) {
       const uint32_t lp = q.pix[slot];
@@ -472,7 +496,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         n_wh = 0;
       }
     }
+    RT_POOL_TICK(4);
+#ifdef RT_DEBUG_KERNEL
+    ++ck[6];
+#endif
   }
+#ifdef RT_DEBUG_KERNEL
+  if (lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_pool_cyc[i], (unsigned long long)ck[i]);
+    atomicAdd(&g_pool_cyc[5], (unsigned long long)(clock64() - ck_begin)); atomicAdd(&g_pool_cyc[6], (unsigned long long)ck[6]);
+  }
+#endif
   if (n_wh > 0u) {
     uint32_t gbase = 0;
     if (lane == 0) gbase = atomicAdd(&C->n_hits[level], n_wh);
