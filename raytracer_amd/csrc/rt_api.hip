@@ -314,13 +314,15 @@ struct rt_scene {
   bool all_opaque = true;
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
-  size_t cap_pixels = 0, cap_queue = 0, cap_out = 0;
+  size_t cap_pixels = 0, cap_queue = 0, cap_hits = 0, cap_out = 0;
   size_t min_queue = 0;          // queue capacity requested after an overflow (rays per level)
+  int retry_attempt = 0;         // rt_render's retry loop: which attempt is running
   size_t overflow_need = 0;      // largest level size seen by the last overflowed frame
   FixRec* d_fix = nullptr; size_t cap_fix = 0, min_fix = 0;   // re-test queue of the fp32 mode
   int sticky_overflow = 0;       // an RT_FLAG_ASYNC frame overflowed since the last rt_sync / blocking rt_render
   hipStream_t copy_stream = nullptr;   // host-output frames: device -> host copies of finished row bands (render_banded)
-  void* d_fb = nullptr;          // cap_pixels*3 doubles (also used as float)
+  void* d_fb = nullptr;          // cap_fb pixels * 3 doubles (also used as float); only frames that do not render straight into the caller's device buffer need it
+  size_t cap_fb = 0;
   void* d_out = nullptr;         // conversion / staging target
   HitRec* d_hits = nullptr;
   // large scenes: hits of level >= 1 are regrouped by grid cell before shading (rt_sort.hpp)
@@ -352,7 +354,7 @@ static void free_workspace(rt_scene* s) {
   for (int i = 0; i < 2; ++i) { if (s->d_qbuf[i]) hipFree(s->d_qbuf[i]); if (s->d_qpix[i]) hipFree(s->d_qpix[i]); }
   s->d_fb = s->d_out = nullptr; s->d_hits = nullptr;
   s->d_qbuf[0] = s->d_qbuf[1] = nullptr; s->d_qpix[0] = s->d_qpix[1] = nullptr;
-  s->cap_pixels = s->cap_queue = s->cap_out = 0;
+  s->cap_pixels = s->cap_queue = s->cap_hits = s->cap_out = s->cap_fb = 0;
 }
 
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
@@ -613,12 +615,14 @@ static int drain(rt_scene* s) {
     const Counters& c = *pf.h_counters;
     if (c.overflow) {
       size_t need = 0;
-      for (int l = 0; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, std::max(c.n_rays[l], c.n_hits[l]));
+      for (int l = 1; l <= MAX_LEVELS; ++l) need = std::max<size_t>(need, c.n_rays[l]);      // (level 0 lives in the hit list only)
       need = std::max<size_t>(need, (size_t)c.seg_need * NSEG);       // the fullest queue segment decides
       s->overflow_need = need;
       // the next frame (blocking retry, or the next async frame) gets larger queues; levels below the truncated
       // one were undercounted, so grow generously
-      s->min_queue = std::max(s->min_queue, std::max(need + need / 4, 2 * s->cap_queue));
+      // (first retry of a call: what the overflowing level asked for plus 15 %; later retries double, because the
+      // levels below a truncated one were undercounted)
+      s->min_queue = std::max(s->min_queue, std::max(need + need * 3 / 20, s->retry_attempt >= 1 ? 2 * s->cap_queue : (size_t)0));
       rc = fail(RT_ERR_QUEUE_OVERFLOW, "bounce queue overflow (a level holds >= %zu rays, capacity %zu): a blocking "
                 "rt_render call grows the queues and retries by itself", need, s->cap_queue);
     }
@@ -628,6 +632,14 @@ static int drain(rt_scene* s) {
       s->min_fix = std::max(s->min_fix, (worst + worst / 4 + 1024) * FIX_QUEUES);
       rc = fail(RT_ERR_QUEUE_OVERFLOW, "re-test queue overflow (a sub-queue holds %zu (hit, light) pairs, capacity %zu): a blocking "
                 "rt_render call grows the queue and retries by itself", worst, s->cap_fix / FIX_QUEUES);
+    }
+    if (getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 22))) {      // fill of the bounce-queue segments (last two levels)
+      for (int par = 0; par < 2; ++par) {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0; unsigned long long sum = 0;
+        for (int q = 0; q < NSEG; ++q) { const uint32_t v = c.segcnt[par][q * 32]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+        fprintf(stderr, "[rt debug] queue segments (level parity %d): min %u, mean %.0f, max %u (+%.1f %%)\n", par, mn, (double)sum / NSEG, mx,
+                sum ? 100.0 * ((double)mx * NSEG / (double)sum - 1.0) : 0.0);
+      }
     }
 #ifdef RT_DEBUG_KERNEL
     if (getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 21))) {
@@ -684,8 +696,17 @@ extern "C" int rt_sync(rt_scene* s) {
   return drain(s);
 }
 
-static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out) {
-  const size_t want_q = std::max<size_t>(2 * pixels + 1024, s->min_queue);
+// Bounce-ray queues: a blocking frame starts with 0.55 slots per pixel and queue (the pool scene's largest bounce
+// level holds 0.42 rays per pixel, its fullest queue segment 17 % more than the mean; at 7680x4320 the workspace is
+// then 3.5 GB instead of 11 GB; RT_QUEUE_SLOTS_PER_PIXEL overrides) and relies on
+// the overflow retry of rt_render, which re-renders with the size the overflowing level asked for; the sizes only
+// ever grow, so later frames of the scene start where the last retry ended.  Frames that cannot be retried
+// (RT_FLAG_ASYNC) get the old worst-case-ish 2 slots per pixel unless the workspace is larger already.
+static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out, bool can_retry, bool need_fb = true) {
+  double per_pixel = can_retry ? 0.55 : 2.0;
+  if (const char* e = getenv("RT_QUEUE_SLOTS_PER_PIXEL")) per_pixel = std::min(64.0, std::max(0.01, atof(e)));
+  const size_t base_q = (size_t)(per_pixel * (double)pixels) + 65536;      // (the constant: small frames fill their 64 segments unevenly)
+  const size_t want_q = std::max<size_t>(base_q, s->min_queue);
   const size_t want_fix = std::max<size_t>(std::max<size_t>(pixels / 8, 65536), s->min_fix);
   if (pixels > s->cap_pixels || want_q > s->cap_queue || want_fix > s->cap_fix) {
     pixels = std::max(pixels, s->cap_pixels);
@@ -693,13 +714,13 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
     free_workspace(s);
     s->d_out = keep_out; s->cap_out = keep_cap;
-    size_t q = (std::max<size_t>(2 * pixels + 1024, s->min_queue) + NSEG - 1) / NSEG * NSEG;   // NSEG equal segments
-    if (q > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
-    HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
-    HIPCHK(hipMalloc(&s->d_hits, q * sizeof(HitRec)));
+    size_t q = (std::max<size_t>(std::max(want_q, s->cap_queue), s->min_queue) + NSEG - 1) / NSEG * NSEG;   // NSEG equal segments
+    const size_t nh = std::max(q, pixels);                                // hit list: level 0 has one ray per pixel
+    if (nh > 0xFFFFFFF0ull) return fail(RT_ERR_INVALID, "row set too large (%zu pixels): render it in parts", pixels);
+    HIPCHK(hipMalloc(&s->d_hits, nh * sizeof(HitRec)));
     if (s->sort_hits) {
-      HIPCHK(hipMalloc(&s->d_hits_sorted, q * sizeof(HitRec)));
-      HIPCHK(hipMalloc(&s->d_sort_keys, q * sizeof(uint16_t)));
+      HIPCHK(hipMalloc(&s->d_hits_sorted, nh * sizeof(HitRec)));
+      HIPCHK(hipMalloc(&s->d_sort_keys, nh * sizeof(uint16_t)));
       // table[bin][block] followed by the per-bin totals
       HIPCHK(hipMalloc(&s->d_sort_table, ((size_t)SORT_BINS * SORT_BLOCKS + SORT_BINS) * sizeof(uint32_t)));
     }
@@ -709,7 +730,14 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     }
     const size_t nfix = std::max<size_t>(std::max<size_t>(pixels / 8, 65536), s->min_fix);
     HIPCHK(hipMalloc(&s->d_fix, nfix * sizeof(FixRec)));
-    s->cap_pixels = pixels; s->cap_queue = q; s->cap_fix = nfix;
+    s->cap_pixels = pixels; s->cap_queue = q; s->cap_hits = nh; s->cap_fix = nfix;
+  }
+  if (need_fb && pixels > s->cap_fb) {
+    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    if (s->d_fb) hipFree(s->d_fb);
+    s->d_fb = nullptr; s->cap_fb = 0;
+    HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
+    s->cap_fb = pixels;
   }
   if (need_out && out_bytes > s->cap_out) {
     int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
@@ -989,7 +1017,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (!s || !camera || !fr || !out) return fail(RT_ERR_INVALID, "rt_render: null pointer");
   std::lock_guard<std::mutex> lk(s->mu);
   int rc = RT_OK;
-  for (int attempt = 0; attempt < 6; ++attempt) {
+  for (int attempt = 0; attempt < 10; ++attempt) {
+    s->retry_attempt = attempt;
     rc = render_locked(s, camera, fr, out, out_is_device, stats);
     if (rc != RT_ERR_QUEUE_OVERFLOW || (fr->flags & RT_FLAG_ASYNC)) break;
     // A level outgrew the queues (more than ~2 live rays per pixel) or the re-test queue was too small: drain()
@@ -1016,13 +1045,13 @@ static int validate_frame(const rt_frame* fr, int out_is_device, int32_t* rows) 
   return rt_rows_in_part(fr->height, fr->block_rows, fr->part, fr->n_parts, rows);
 }
 
-static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queue, size_t cap_fix) {
+static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queue, size_t cap_hits, size_t cap_fix) {
   FrameParams fp;
   fp.rs.W = fr->width; fp.rs.H = fr->height; fp.rs.block_rows = fr->block_rows; fp.rs.part = fr->part;
   fp.rs.n_parts = fr->n_parts; fp.rs.rows = rows;
   // 8x8 pixel tiles per wave at level 0; the numpy-stream mode needs hits in ascending pixel order
   fp.rs.tiled = (fr->jitter_mode == RT_JITTER_PIXEL_KEYED && !getenv("RT_NO_TILES")) ? 1 : 0; fp.rs.pad = 0;
-  fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)cap_queue;
+  fp.n_shadow = fr->n_shadow; fp.max_depth = fr->max_depth; fp.seed = fr->jitter_seed; fp.queue_cap = (uint32_t)cap_queue; fp.hit_cap = (uint32_t)cap_hits;
   fp.debug = getenv("RT_DEBUG_STATS") ? (uint32_t)std::max(1, atoi(getenv("RT_DEBUG_STATS"))) : 0u;
   fp.sequential = (fr->flags & RT_FLAG_SEQUENTIAL) ? 1u : 0u;
   fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
@@ -1044,7 +1073,7 @@ static int render_banded(rt_scene* s, const rt_camera* camera, const rt_frame* f
   const size_t fsz = fb_is_double ? 8 : 4;
   const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
   const size_t pixels = (size_t)rows * fr->width;
-  int rc = ensure_workspace(s, pixels, pixels * 3 * esz, !native);
+  int rc = ensure_workspace(s, pixels, pixels * 3 * esz, !native, true);
   if (rc != RT_OK) return rc;
   rc = drain(s); if (rc != RT_OK) return rc;
   if (!s->copy_stream) HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
@@ -1066,7 +1095,7 @@ static int render_banded(rt_scene* s, const rt_camera* camera, const rt_frame* f
     pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
     pf.precision = fr->precision; pf.timing = (fr->flags & RT_FLAG_TIMING) != 0;
     pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
-    const FrameParams fp = make_params(&bf, brows, s->cap_queue, s->cap_fix);
+    const FrameParams fp = make_params(&bf, brows, s->cap_queue, s->cap_hits, s->cap_fix);
     char* fb = (char*)s->d_fb + off_px * 3 * fsz;
     rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, &bf, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, &bf, (float*)fb, &pf);
     if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
@@ -1119,7 +1148,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);
   const bool direct = native && out_is_device;            // render straight into the caller's buffer
   const bool need_out = !native;                           // conversion target on the device
-  rc = ensure_workspace(s, pixels, nval * esz, need_out && !out_is_device);
+  rc = ensure_workspace(s, pixels, nval * esz, need_out && !out_is_device, !(fr->flags & RT_FLAG_ASYNC), !direct);
   if (rc != RT_OK) return rc;
   if (s->pending.size() >= 48) { rc = drain(s); if (rc != RT_OK) return rc; }
 
@@ -1130,7 +1159,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   if (s->h_slots.empty()) { Counters* h = nullptr; HIPCHK(hipHostMalloc(&h, sizeof(Counters))); s->h_slots.push_back(h); }
   pf.h_counters = s->h_slots.back(); s->h_slots.pop_back();
 
-  const FrameParams fp = make_params(fr, rows, s->cap_queue, s->cap_fix);
+  const FrameParams fp = make_params(fr, rows, s->cap_queue, s->cap_hits, s->cap_fix);
   DevCamera cam = to_dev_camera(camera);
 
   void* fb = direct ? out : s->d_fb;
@@ -1219,7 +1248,7 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   pf.user = stats; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
   pf.n_cells = fr->n_shadow > 1 ? fr->n_shadow * fr->n_shadow : 1;
   pf.precision = fr->precision; pf.timing = false;
-  const FrameParams fp = make_params(fr, rows, cap, wb.cap_fix);
+  const FrameParams fp = make_params(fr, rows, cap, cap, wb.cap_fix);
   const DevCamera cam = to_dev_camera(camera);
   const bool fb_is_double = fr->precision == RT_FP64;
   const bool native = (fb_is_double && fr->out_format == RT_OUT_F64) || (!fb_is_double && fr->out_format == RT_OUT_F32);

@@ -92,7 +92,8 @@ struct FrameParams {
   RowSet rs;
   int32_t n_shadow, max_depth;
   uint32_t seed;
-  uint32_t queue_cap;
+  uint32_t queue_cap;    // slots of each bounce-ray queue
+  uint32_t hit_cap;      // slots of the hit list (>= pixels of the row set: level 0 has one ray per pixel, and >= queue_cap)
   uint32_t debug;        // RT_DEBUG_STATS=1: kernels count events into Counters::queries (fp32 mode)
   uint32_t sequential;   // RT_FLAG_SEQUENTIAL: semantics of the reference's per-pixel render()
   double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
   uint32_t n_chunks;
   if (level == 0) {
     uint32_t count0 = C->n_rays[0];
-    if (count0 > fp.queue_cap) count0 = fp.queue_cap;
+    if (count0 > fp.hit_cap) count0 = fp.hit_cap;
     n_chunks = (count0 + CHUNK - 1) / CHUNK;
     if (threadIdx.x == 0) { s_segfirst[0] = 0; s_segfirst[1] = n_chunks; }
   } else {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
     uint32_t slot0, count;       // slots [slot0, count) of this chunk are rays (count is an END, like the old level size)
     if (level == 0) {
       slot0 = chunk * CHUNK;
-      count = C->n_rays[0]; if (count > fp.queue_cap) count = fp.queue_cap;
+      count = C->n_rays[0]; if (count > fp.hit_cap) count = fp.hit_cap;
     } else {
       int lo_ = 0, hi_ = NSEG;                     // last segment whose first chunk id is <= chunk
       while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (s_segfirst[mid] <= chunk) lo_ = mid; else hi_ = mid; }
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
     __syncthreads();
     const uint32_t gbase = s_base;
     for (uint32_t i = threadIdx.x; i < n_local; i += BLOCK) {
-      if (gbase + i < fp.queue_cap) hits[gbase + i] = s_hits[i];
+      if (gbase + i < fp.hit_cap) hits[gbase + i] = s_hits[i];
       else C->overflow = 1u;
     }
     __syncthreads();
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         if (lane == 0) gbase = atomicAdd(&C->n_hits[level], n_wh);
         gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
         for (uint32_t i = (uint32_t)lane; i < n_wh; i += 64u) {
-          if (gbase + i < fp.queue_cap) hits[gbase + i] = whits[i];
+          if (gbase + i < fp.hit_cap) hits[gbase + i] = whits[i];
           else C->overflow = 1u;
         }
         n_wh = 0;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     if (lane == 0) gbase = atomicAdd(&C->n_hits[level], n_wh);
     gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
     for (uint32_t i = (uint32_t)lane; i < n_wh; i += 64u) {
-      if (gbase + i < fp.queue_cap) hits[gbase + i] = whits[i];
+      if (gbase + i < fp.hit_cap) hits[gbase + i] = whits[i];
       else C->overflow = 1u;
     }
   }
@@ -528,12 +529,19 @@ __device__ __forceinline__ bool seq_background_term(const FrameParams& fp, int l
 
 // Segment for the children of 64-hit chunk `chunk` of a level with `count` hits: groups of G consecutive chunks
 // share a segment (their children stay together in the queue: neighbouring hits -> neighbouring rays for the next
-// k_trace), the groups are dealt round-robin, and G is chosen so that every segment receives >= 8 groups whenever
-// the level has that many chunks — the segments then fill evenly whatever wave happens to shade which chunk.
+// k_trace), the groups are dealt round-robin, and G is chosen so that every segment receives ~128 groups spread over
+// the whole image whenever the level has that many chunks — the segments then fill evenly (within a few percent)
+// whatever the image looks like and whatever wave happens to shade which chunk, so the queues need little headroom.
 __device__ __forceinline__ uint32_t spawn_segment(uint32_t chunk, uint32_t count) {
   const uint32_t n_chunks = (count + 63u) >> 6;
-  const uint32_t G = max(1u, n_chunks / (uint32_t)(NSEG * 8));
-  return (chunk / G) & (uint32_t)(NSEG - 1);
+#ifndef RT_SPAWN_GROUPS
+#define RT_SPAWN_GROUPS 128
+#endif
+  const uint32_t G = max(1u, n_chunks / (uint32_t)(NSEG * RT_SPAWN_GROUPS));
+  // round-robin with a skew per round: a plain g % NSEG hands a segment the same image columns in every round
+  // (a 3840-wide frame has 32 groups per tile row), and its fill then follows the columns' content (measured +16 %)
+  const uint32_t g = chunk / G;
+  return (g + (g / (uint32_t)NSEG) * 37u) & (uint32_t)(NSEG - 1);
 }
 
 // Reserve queue slots for the children of one wave's hits: ONE atomic per wave on the counter of segment `seg`.  Returns physical slots (segment * seg_cap + offset), 0xFFFFFFFF = no slot
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   uint32_t count = C->n_hits[level];
-  if (count > fp.queue_cap) count = fp.queue_cap;
+  if (count > fp.hit_cap) count = fp.hit_cap;
   const uint32_t lane = __lane_id();
   for (;;) {
     uint32_t base = grab64(&C->work_shade[level]);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   const float scene_m = sc.scene_m;   // scales the fp32 slack of the node tests
   uint32_t count = C->n_hits[level];
-  if (count > fp.queue_cap) count = fp.queue_cap;
+  if (count > fp.hit_cap) count = fp.hit_cap;
   const uint32_t lane = __lane_id();
   const int n_sh = fp.n_shadow;
   const int n_cells = n_sh > 1 ? n_sh * n_sh : 1;

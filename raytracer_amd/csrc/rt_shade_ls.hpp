@@ -408,7 +408,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   float umbra_t0_max = 3.0e38f;                              // 1000 * (smallest sphere radius)^2
   for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
   uint32_t count = C->n_hits[level];
-  if (count > fp.queue_cap) count = fp.queue_cap;
+  if (count > fp.hit_cap) count = fp.hit_cap;
   const float inv_cells = 1.0f / (float)n_cells;
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;

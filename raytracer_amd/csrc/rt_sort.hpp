@@ -28,7 +28,7 @@ struct SortGrid {                     // cell of p: clamp((p - lo) * inv, 0, n -
 };
 
 __device__ __forceinline__ void sort_range(uint32_t count, const FrameParams& fp, uint32_t* begin, uint32_t* end) {
-  if (count > fp.queue_cap) count = fp.queue_cap;
+  if (count > fp.hit_cap) count = fp.hit_cap;
   const uint32_t chunk = (count + SORT_BLOCKS - 1) / SORT_BLOCKS;
   const uint32_t b = blockIdx.x * chunk;
   *begin = b < count ? b : count;
