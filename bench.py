@@ -293,9 +293,14 @@ def main():
                     traffic = rec.get("hbm_bytes_per_shade_launch")
                     if world == 1 and rec.get("executed_fp32_flops_per_frame"):
                         ex = rec["executed_fp32_flops_per_frame"] / (shade_ms * 1e-3) / 1e12
+                        ex_hi = rec.get("executed_fp32_flops_per_frame_upper", rec["executed_fp32_flops_per_frame"]) / (shade_ms * 1e-3) / 1e12
+                        issue_peak = rec.get("valu_issue_peak_Tinstr_per_s")
                         executed = {"tflops": round(ex, 2), "frac": round(ex / peak, 4),
+                                    "tflops_if_all_packed": round(ex_hi, 2), "frac_if_all_packed": round(ex_hi / peak, 4),
+                                    "packed_static_share_of_fp32_add_mul_fma": rec.get("packed_static_share_of_fp32_add_mul_fma"),
                                     "valu_wave_instructions_per_frame": rec.get("valu_wave_instructions_per_frame"),
-                                    "valu_issue_fraction_of_measured_peak": rec.get("valu_issue_fraction_of_measured_peak"),
+                                    "valu_issue_fraction_of_measured_peak": round(rec["valu_wave_instructions_per_frame"] / (shade_ms * 1e-3) / 1e12 / issue_peak, 4)
+                                    if issue_peak and rec.get("valu_wave_instructions_per_frame") else None,
                                     "valu_active_fraction_of_wave_cycles": rec.get("valu_active_fraction_of_wave_cycles"),
                                     "waves_per_simd": rec.get("waves_per_simd"), "round": rec.get("round"),
                                     "source": rec.get("source", "profiles/pmc_latest.json (rocprofv3 --pmc)")}
