@@ -670,9 +670,9 @@ __device__ __forceinline__ double soft_shadow_exact(const DevScene& sc, const Pr
 // The shadow ray of grid cell `cell` of light li from the shadow origin p, formed exactly as the reference forms it
 // (ray_tracer.py:184-235, fp64, pixel-keyed jitter): origin p + dir*1e-6, unit direction, length |S - p| - 1e-6.
 struct ExactRay { d3 so, dir; double maxdist; };
-__device__ __forceinline__ ExactRay exact_shadow_ray(const DevScene& sc, d3 p, int li, int n_sh, uint32_t seed, uint32_t gpix,
-                                                     uint32_t depth, int cell) {
-  const double* lg = sc.lights + LIGHT_STRIDE * li;
+__device__ __forceinline__ ExactRay exact_shadow_ray_l(const double* __restrict__ lights, d3 p, int li, int n_sh, uint32_t seed, uint32_t gpix,
+                                                       uint32_t depth, int cell) {
+  const double* lg = lights + LIGHT_STRIDE * li;
   const d3 Lp = mk3(lg[0], lg[1], lg[2]);
   d3 sp = Lp;
   if (n_sh > 1) {
@@ -708,6 +708,10 @@ __device__ __forceinline__ bool basis_switch_exact(const DevScene& sc, d3 p, int
   const double* lg = sc.lights + LIGHT_STRIDE * li;
   const d3 tl = mk3(lg[0] - p.x, lg[1] - p.y, lg[2] - p.z);
   return fabs(tl.x / norm3(tl)) >= 0.9;
+}
+__device__ __forceinline__ ExactRay exact_shadow_ray(const DevScene& sc, d3 p, int li, int n_sh, uint32_t seed, uint32_t gpix,
+                                                     uint32_t depth, int cell) {
+  return exact_shadow_ray_l(sc.lights, p, li, n_sh, seed, gpix, depth, cell);
 }
 
 // The crossings of ONE primitive by a shadow ray, each decided in fp64 with the arithmetic of the reference's
@@ -748,6 +752,18 @@ __device__ __forceinline__ void exact_crossings(const Prim& pr, d3 o, d3 d, doub
     *in2 = (tmax >= HIT_EPS) & (tmax < maxdist) & !(*in1 & !(tmax - (tmin + EPS) >= HIT_EPS));
   }
 }
+
+// The exact decision for ONE (sample, primitive) pair, out of line: the fp32 shade kernels call it for the ~1e-5 of
+// their tests that fall within the fp32 error bound.  A real function call on purpose — inlined at every test site it
+// cost k_shade_fast 83 spilled VGPRs and 40 % more code in the loops that never need it.  Returns in1 | in2 << 1.
+__device__ __attribute__((noinline)) uint32_t exact_retest(const double* __restrict__ lights, const Prim* prim, double px, double py, double pz,
+                                                           int li, int n_sh, uint32_t seed, uint32_t gpix, uint32_t depth, int cell) {
+  const ExactRay er = exact_shadow_ray_l(lights, mk3(px, py, pz), li, n_sh, seed, gpix, depth, cell);
+  bool e1 = false, e2 = false;
+  exact_crossings(*prim, er.so, er.dir, er.maxdist, &e1, &e2);
+  return (e1 ? 1u : 0u) | (e2 ? 2u : 0u);
+}
+
 
 struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading result of one hit
 

@@ -249,25 +249,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             if (OPAQUE) { t_ = (in1 | in2) ? 0.0f : t_; }
             else { t_ *= in1 ? tau : 1.0f; t_ *= in2 ? tau : 1.0f; }
           };
-          // Samples whose decision for primitive s_ lay within the fp32 error bound were left out above: decide them in
-          // fp64 from the exact shadow ray, here and now (rare: ~1e-5 of the tests; the wave pays the fp64 code only when
-          // one of its lanes has such a sample).  (CH <= 25 samples: one bit each.)
-          auto retest = [&](const Prim& s_, uint32_t fmask, float tau) __attribute__((always_inline)) {
-            while (__any(fmask != 0u)) {                      // (far hits: usually every sample of the chunk, one per turn)
-              bool e1 = false, e2 = false;
-              const int s_star = fmask ? __ffs((int)fmask) - 1 : -1;
-              if (fmask) {
-                const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, c * CH + s_star);
-                exact_crossings(s_, er.so, er.dir, er.maxdist, &e1, &e2);
-              }
-#pragma unroll
-              for (int s = 0; s < CH; ++s)
-                if (s == s_star) apply(tr[s], e1, e2, tau);
-              fmask &= fmask - 1u;
+          // Samples whose decision for a primitive lay within the fp32 error bound are left out of the products above and
+          // decided in fp64 from the exact shadow ray AFTER the chunk's primitives are through (rare: ~1e-5 of the tests): up
+          // to two (primitive, sample mask) entries per lane and chunk are remembered in registers; a third one makes the
+          // whole (hit, light) pair undecided (-> re-test queue).  ONE fp64 site per chunk instead of one per test site:
+          // inlined behind every sample block the exact code cost 83 spilled VGPRs and 5 ms of a 22 ms frame.
+          int dk0 = -1, dk1 = -1; uint32_t dm0 = 0u, dm1 = 0u;
+          auto retest = [&](int k_, uint32_t fmask) __attribute__((always_inline)) {
+            if (fmask != 0u) {
+              if (dk0 < 0) { dk0 = k_; dm0 = fmask; }
+              else if (dk1 < 0) { dk1 = k_; dm1 = fmask; }
+              else unc = 1.0f;
             }
           };
           // per-primitive blocks: everything that depends on (hit, primitive) once, then CH samples
-          auto do_sphere = [&](const Prim& s_) __attribute__((always_inline)) {   // sphere.py:49-71
+          auto do_sphere = [&](const Prim& s_, int k_) __attribute__((always_inline)) {   // sphere.py:49-71
             const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
             const float cc = (float)(((ocx * ocx + ocy * ocy) + ocz * ocz) - s_.a[4]);
             const f3 oc = mkf((float)ocx, (float)ocy, (float)ocz);
@@ -308,9 +304,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!f) apply(tr[s], in1, in2, tau);
               fmask |= f ? (1u << s) : 0u;
             }
-            retest(s_, fmask, tau);
+            retest(k_, fmask);
           };
-          auto do_box = [&](const Prim& s_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
+          auto do_box = [&](const Prim& s_, int k_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
             const f3 lo = mkf((float)(s_.a[0] - p.x), (float)(s_.a[1] - p.y), (float)(s_.a[2] - p.z));
             const f3 hi = mkf((float)(s_.a[3] - p.x), (float)(s_.a[4] - p.y), (float)(s_.a[5] - p.z));
             const float tau = OPAQUE ? 0.0f : (float)sc.mats[MAT_STRIDE * s_.mat + 10];
@@ -351,7 +347,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!f) apply(tr[s], in1, in2, tau);
               fmask |= f ? (1u << s) : 0u;
             }
-            retest(s_, fmask, tau);
+            retest(k_, fmask);
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
             if (!cand.has(k)) continue;
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!f) apply(tr[s], in1, false, tau);
               fmask |= f ? (1u << s) : 0u;
             }
-            retest(s_, fmask, tau);
+            retest(k, fmask);
           }
           if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {
             // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
@@ -535,8 +531,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
                   const int k = (int)my_cand[e * BLOCK];
                   if (RT_DBG(fp)) ++dbg_cands;
                   if ((RT_DBG(fp) & 65536u) && exact_crossed(k)) ++audit_crossed;
-                  if (k < sc.nS) do_sphere(P[k]);
-                  else if (HAS_BOX) do_box(P[k]);
+                  if (k < sc.nS) do_sphere(P[k], k);
+                  else if (HAS_BOX) do_box(P[k], k);
                 }
               }
               n_cand = 0;
@@ -576,10 +572,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             }
           } else {
             for (int k = 0; k < sc.nS; ++k)
-              if (cand.has(k)) do_sphere(P[k]);
+              if (cand.has(k)) do_sphere(P[k], k);
             if (HAS_BOX)
               for (int k = sc.nS + sc.nP, e = sc.n; k < e; ++k)
-                if (cand.has(k)) do_box(P[k]);
+                if (cand.has(k)) do_box(P[k], k);
+          }
+          while (__any(dm0 != 0u)) {                         // the deferred exact decisions of this chunk, one sample per turn
+            bool e1 = false, e2 = false;
+            float tau = 0.0f;
+            const int s_star = dm0 ? __ffs((int)dm0) - 1 : -1;
+            if (dm0) {
+              const Prim& s_ = P[dk0];
+              if (!OPAQUE) tau = (float)sc.mats[MAT_STRIDE * s_.mat + 10];
+              const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, c * CH + s_star);
+              exact_crossings(s_, er.so, er.dir, er.maxdist, &e1, &e2);
+            }
+#pragma unroll
+            for (int s = 0; s < CH; ++s)
+              if (s == s_star) apply(tr[s], e1, e2, tau);
+            dm0 &= dm0 - 1u;
+            if (dm0 == 0u) { dk0 = dk1; dm0 = dm1; dk1 = -1; dm1 = 0u; }
           }
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
