@@ -43,16 +43,23 @@ static int fail(int code, const char* fmt, ...) {
                                       "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// The ABI never throws: every extern "C" entry point is a function-try-block (the bodies use std::vector / deque /
+// string; a std::bad_alloc crossing into ctypes would terminate the caller's process).
+#define RT_CATCH_ALL                                                                               \
+  catch (const std::bad_alloc&) { return fail(RT_ERR_NOMEM, "out of host memory"); }               \
+  catch (const std::exception& e_) { return fail(RT_ERR_HIP, "internal error: %s", e_.what()); }   \
+  catch (...) { return fail(RT_ERR_HIP, "internal error"); }
+
 extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
 
-extern "C" int rt_device_count(int* count) {
+extern "C" int rt_device_count(int* count) try {
   if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null pointer");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) { *count = 0; return fail(RT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
   *count = n;
   return RT_OK;
-}
+} RT_CATCH_ALL
 
 static int static_scratch_for(int device, unsigned char** out);   // rt_render_static, below
 
@@ -357,7 +364,7 @@ static void free_workspace(rt_scene* s) {
   s->cap_pixels = s->cap_queue = s->cap_hits = s->cap_out = s->cap_fb = 0;
 }
 
-extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) try {
   if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null pointer");
   *out = nullptr;
   if (desc->n_surfaces < 0 || desc->n_materials < 0 || desc->n_lights < 0)
@@ -526,9 +533,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   }
   *out = s;
   return RT_OK;
-}
+} RT_CATCH_ALL
 
-extern "C" void rt_scene_destroy(rt_scene* s) {
+extern "C" void rt_scene_destroy(rt_scene* s) try {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
@@ -553,18 +560,18 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->copy_stream) hipStreamDestroy(s->copy_stream);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
-}
+} catch (...) { }
 
-extern "C" int rt_scene_set_stream(rt_scene* s, void* hip_stream) {
+extern "C" int rt_scene_set_stream(rt_scene* s, void* hip_stream) try {
   if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_stream: null scene");
   std::lock_guard<std::mutex> lk(s->mu);
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
   return RT_OK;
-}
+} RT_CATCH_ALL
 
-extern "C" int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part, int32_t n_parts, int32_t* rows) {
+extern "C" int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part, int32_t n_parts, int32_t* rows) try {
   if (!rows || height < 0 || block_rows <= 0) return fail(RT_ERR_INVALID, "rt_rows_in_part: bad arguments");
   if (n_parts <= 1) { *rows = height; return RT_OK; }
   if (part < 0 || part >= n_parts) return fail(RT_ERR_INVALID, "rt_rows_in_part: part %d of %d", part, n_parts);
@@ -574,7 +581,7 @@ extern "C" int rt_rows_in_part(int32_t height, int32_t block_rows, int32_t part,
   if (tail && (full_blocks % n_parts) == part) r += tail;
   *rows = r;
   return RT_OK;
-}
+} RT_CATCH_ALL
 
 // Fold a finished frame's device counters (and event timings) into the caller's rt_stats.
 static void fill_stats(PendingFrame& pf, const Counters& c, rt_stats* out) {
@@ -690,11 +697,15 @@ static int drain(rt_scene* s) {
   return rc;
 }
 
-extern "C" int rt_sync(rt_scene* s) {
+extern "C" int rt_sync(rt_scene* s) try {
   if (!s) return fail(RT_ERR_INVALID, "rt_sync: null scene");
   std::lock_guard<std::mutex> lk(s->mu);
-  return drain(s);
-}
+  int rc = drain(s);
+  if (rc == RT_OK && s->sticky_overflow)      // an async frame's overflow that an internal drain (workspace growth) had to swallow
+    rc = fail(RT_ERR_QUEUE_OVERFLOW, "an earlier RT_FLAG_ASYNC frame overflowed its bounce queues (they have been grown since): render it again");
+  s->sticky_overflow = 0;
+  return rc;
+} RT_CATCH_ALL
 
 // Bounce-ray queues: a blocking frame starts with 0.55 slots per pixel and queue (the pool scene's largest bounce
 // level holds 0.42 rays per pixel, its fullest queue segment 17 % more than the mean; at 7680x4320 the workspace is
@@ -710,7 +721,7 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
   const size_t want_fix = std::max<size_t>(std::max<size_t>(pixels / 8, 65536), s->min_fix);
   if (pixels > s->cap_pixels || want_q > s->cap_queue || want_fix > s->cap_fix) {
     pixels = std::max(pixels, s->cap_pixels);
-    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    int rc = drain(s); if (rc == RT_ERR_QUEUE_OVERFLOW) s->sticky_overflow = 1; else if (rc != RT_OK) return rc;
     void* keep_out = s->d_out; size_t keep_cap = s->cap_out; s->d_out = nullptr;
     free_workspace(s);
     s->d_out = keep_out; s->cap_out = keep_cap;
@@ -733,14 +744,14 @@ static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool n
     s->cap_pixels = pixels; s->cap_queue = q; s->cap_hits = nh; s->cap_fix = nfix;
   }
   if (need_fb && pixels > s->cap_fb) {
-    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    int rc = drain(s); if (rc == RT_ERR_QUEUE_OVERFLOW) s->sticky_overflow = 1; else if (rc != RT_OK) return rc;
     if (s->d_fb) hipFree(s->d_fb);
     s->d_fb = nullptr; s->cap_fb = 0;
     HIPCHK(hipMalloc(&s->d_fb, pixels * 3 * sizeof(double)));
     s->cap_fb = pixels;
   }
   if (need_out && out_bytes > s->cap_out) {
-    int rc = drain(s); if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) return rc;
+    int rc = drain(s); if (rc == RT_ERR_QUEUE_OVERFLOW) s->sticky_overflow = 1; else if (rc != RT_OK) return rc;
     if (s->d_out) hipFree(s->d_out);
     s->d_out = nullptr; s->cap_out = 0;
     HIPCHK(hipMalloc(&s->d_out, out_bytes));
@@ -1013,7 +1024,7 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
                          rt_stats* stats);
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out, int out_is_device,
-                         rt_stats* stats) {
+                         rt_stats* stats) try {
   if (!s || !camera || !fr || !out) return fail(RT_ERR_INVALID, "rt_render: null pointer");
   std::lock_guard<std::mutex> lk(s->mu);
   int rc = RT_OK;
@@ -1025,7 +1036,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, const rt_frame* f
     // has raised min_queue / min_fix, render the frame again (rendering is deterministic).
   }
   return rc;
-}
+} RT_CATCH_ALL
 
 // Argument checks shared by rt_render and rt_render_static; *rows = rows of the frame's row set.
 static int validate_frame(const rt_frame* fr, int out_is_device, int32_t* rows) {
@@ -1150,7 +1161,10 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   const bool need_out = !native;                           // conversion target on the device
   rc = ensure_workspace(s, pixels, nval * esz, need_out && !out_is_device, !(fr->flags & RT_FLAG_ASYNC), !direct);
   if (rc != RT_OK) return rc;
-  if (s->pending.size() >= 48) { rc = drain(s); if (rc != RT_OK) return rc; }
+  if (s->pending.size() >= 48) {      // (an old async frame's overflow is not this call's error: rt_sync reports it)
+    rc = drain(s);
+    if (rc == RT_ERR_QUEUE_OVERFLOW) s->sticky_overflow = 1; else if (rc != RT_OK) return rc;
+  }
 
   PendingFrame pf;
   pf.user = stats; pf.levels = fr->max_depth + 1; pf.n_lights = s->ds.nL;
@@ -1170,12 +1184,25 @@ static int render_locked(rt_scene* s, const rt_camera* camera, const rt_frame* f
   }
   if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
 
+  // a failure after the launches: the pinned counter slot and the frame's events go back to their pools
+  auto give_back = [&](hipError_t e_, const char* what) {
+    hipStreamSynchronize(s->stream);
+    for (EventPair& ep : pf.events) { s->event_pool.push_back(ep.a); s->event_pool.push_back(ep.b); }
+    s->h_slots.push_back(pf.h_counters);
+    return fail(RT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e_));
+  };
   if (!direct) {
     void* dst = out_is_device ? out : (native ? nullptr : s->d_out);
     if (!native) launch_convert(s, &pf, fb, fb_is_double, fr->out_format, dst, nval);
-    if (!out_is_device) HIPCHK(hipMemcpyAsync(out, native ? fb : s->d_out, nval * esz, hipMemcpyDeviceToHost, s->stream));
+    if (!out_is_device) {
+      const hipError_t e_ = hipMemcpyAsync(out, native ? fb : s->d_out, nval * esz, hipMemcpyDeviceToHost, s->stream);
+      if (e_ != hipSuccess) return give_back(e_, "copy of the frame to the host");
+    }
   }
-  HIPCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+  {
+    const hipError_t e_ = hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream);
+    if (e_ != hipSuccess) return give_back(e_, "copy of the frame's counters");
+  }
   s->pending.push_back(std::move(pf));
   if (fr->flags & RT_FLAG_ASYNC) return RT_OK;
   return drain(s);
@@ -1209,7 +1236,7 @@ static int static_scratch_for(int device, unsigned char** out) {
   return RT_OK;
 }
 
-extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out_device, rt_stats* stats) {
+extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_frame* fr, void* out_device, rt_stats* stats) try {
   if (!s || !camera || !fr || !out_device) return fail(RT_ERR_INVALID, "rt_render_static: null pointer");
   std::lock_guard<std::mutex> lk(s->mu);
   int32_t rows = 0;
@@ -1272,17 +1299,17 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   }
   if (stats) fill_stats(pf, c, stats);
   return RT_OK;
-}
+} RT_CATCH_ALL
 
 // Pinned host memory for output frames (hipHostMalloc): device -> host copies into it run at PCIe speed and
 // asynchronously; into pageable memory they are staged by the runtime at a fraction of that.
-extern "C" int rt_host_alloc(size_t bytes, void** out) {
+extern "C" int rt_host_alloc(size_t bytes, void** out) try {
   if (!out) return fail(RT_ERR_INVALID, "rt_host_alloc: null pointer");
   *out = nullptr;
   hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
   if (e != hipSuccess) { *out = nullptr; return fail(RT_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
   return RT_OK;
-}
+} RT_CATCH_ALL
 extern "C" void rt_host_free(void* p) { if (p) hipHostFree(p); }
 
 // ------------------------------------------------------------------- utility exports -----------
@@ -1302,7 +1329,7 @@ struct DevBuf {
 };
 
 extern "C" int rt_nearest_hit(rt_scene* s, const double* origins, const double* dirs, int64_t M, double* t_out,
-                              int32_t* idx_out, double* normals_out) {
+                              int32_t* idx_out, double* normals_out) try {
   if (!s || M < 0 || (M > 0 && (!origins || !dirs || !t_out || !idx_out || !normals_out)))
     return fail(RT_ERR_INVALID, "rt_nearest_hit: bad arguments");
   if (M == 0) return RT_OK;
@@ -1320,10 +1347,10 @@ extern "C" int rt_nearest_hit(rt_scene* s, const double* origins, const double* 
     HIPCHK(hipStreamSynchronize(s->stream));
     return RT_OK;
   });
-}
+} RT_CATCH_ALL
 
 extern "C" int rt_shadow_transmission(rt_scene* s, const double* origins, const double* dirs, const double* max_dist,
-                                      int64_t M, double* out) {
+                                      int64_t M, double* out) try {
   if (!s || M < 0 || (M > 0 && (!origins || !dirs || !max_dist || !out)))
     return fail(RT_ERR_INVALID, "rt_shadow_transmission: bad arguments");
   if (M == 0) return RT_OK;
@@ -1340,10 +1367,10 @@ extern "C" int rt_shadow_transmission(rt_scene* s, const double* origins, const 
     HIPCHK(hipStreamSynchronize(s->stream));
     return RT_OK;
   });
-}
+} RT_CATCH_ALL
 
 extern "C" int rt_camera_rays(rt_scene* s, const rt_camera* camera, int32_t W, int32_t H, int32_t y0, int32_t y1,
-                              double* origins_out, double* dirs_out) {
+                              double* origins_out, double* dirs_out) try {
   if (!s || !camera || W <= 0 || H <= 0 || y0 < 0 || y1 < y0 || !origins_out || !dirs_out)
     return fail(RT_ERR_INVALID, "rt_camera_rays: bad arguments");
   const int64_t M = (int64_t)(y1 - y0) * W;
@@ -1359,4 +1386,4 @@ extern "C" int rt_camera_rays(rt_scene* s, const rt_camera* camera, int32_t W, i
     HIPCHK(hipStreamSynchronize(s->stream));
     return RT_OK;
   });
-}
+} RT_CATCH_ALL

@@ -5,8 +5,9 @@
 // step is paid for the slowest lane, node and bound loads do not coalesce) and the wave-level leaf
 // list of k_shade_fast overflows.  A counting sort by the grid cell of the hit point makes waves
 // compact again; the children they spawn inherit the order, which helps the next level's k_trace.
-// The shaded values do not depend on the order (jitter is keyed by pixel/level/light, framebuffer
-// updates are atomic adds), so this is a pure scheduling step — it has no counterpart in the
+// Each hit's shaded value does not depend on the order (jitter is keyed by pixel/level/light); the frame is the
+// same up to accumulation-order rounding (framebuffer updates are floating-point atomic adds, and the scatter's LDS
+// cursors hand out slots in whatever order the lanes arrive), so this is a pure scheduling step — it has no counterpart in the
 // reference, whose batches are NumPy arrays in parent order (ray_tracer.py:491-515).
 //
 // Three launches: per-block histograms in LDS -> table[bin][block] (+ per-bin totals, one global atomic
