@@ -160,6 +160,19 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, v
 #define RT_STATIC_MAX_PIXELS 131072
 int rt_render_static(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, void* out_device, rt_stats* stats);
 
+/* ONE frame rendered by several scene handles of this process, one per GPU (the same scene created with
+ * rt_scene_create on each device): handle i renders the interleaved row blocks i, i + n, i + 2n, ... of `block_rows`
+ * rows (frame->part / n_parts are ignored and set per handle), all handles at once, and every device copies its
+ * blocks straight into `out` (one strided copy per device, over xGMI peer access when `out` is device memory on
+ * another GPU, over PCIe when it is host memory).  No collective: the path has no exchange step (pixel-keyed jitter
+ * makes rows independent).  Replaces the per-tile use of camera.py:75-104 (generate_rays_for_rows) + the caller's own
+ * reassembly; SURVEY.md 8(b) names it as the multi-GPU boundary for callers without torch.distributed.
+ * out: (height, width, 3) of frame->out_format, host memory (out_is_device = 0; pinned recommended) or device memory
+ * of scenes[0]'s GPU (out_is_device = 1).  Pixel-keyed jitter only.  stats (may be NULL): summed over the handles.
+ * Blocking; a handle whose bounce queues overflow renders its rows again by itself. */
+int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_camera* camera, const rt_frame* frame, void* out,
+                    int out_is_device, rt_stats* stats);
+
 /* Pinned (page-locked) host memory for output frames.  rt_render copies a host-output frame band by band while the
  * next band renders; into pinned memory those copies run asynchronously at PCIe speed.  No counterpart in the
  * reference, whose image is a NumPy array (ray_tracer.py:599): raytracer_amd.render wraps these buffers as arrays. */

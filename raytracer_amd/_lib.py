@@ -17,7 +17,7 @@ RT_MAX_LEVELS = 32
 RT_STATIC_MAX_PIXELS = 131072
 
 EXPORTS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_stream",
-           "rt_sync", "rt_rows_in_part", "rt_render", "rt_render_static", "rt_host_alloc", "rt_host_free", "rt_nearest_hit", "rt_shadow_transmission", "rt_camera_rays"]
+           "rt_sync", "rt_rows_in_part", "rt_render", "rt_render_static", "rt_render_multi", "rt_host_alloc", "rt_host_free", "rt_nearest_hit", "rt_shadow_transmission", "rt_camera_rays"]
 
 
 class SceneDesc(C.Structure):
@@ -85,6 +85,8 @@ def load():
     lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Frame), C.c_void_p, C.c_int,
                               C.POINTER(Stats)]
     lib.rt_render_static.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Frame), C.c_void_p, C.POINTER(Stats)]
+    lib.rt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CameraDesc), C.POINTER(Frame), C.c_void_p, C.c_int,
+                                    C.POINTER(Stats)]
     lib.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     lib.rt_host_free.argtypes = [C.c_void_p]
     lib.rt_host_free.restype = None

@@ -331,6 +331,7 @@ struct rt_scene {
   void* d_fb = nullptr;          // cap_fb pixels * 3 doubles (also used as float); only frames that do not render straight into the caller's device buffer need it
   size_t cap_fb = 0;
   void* d_out = nullptr;         // conversion / staging target
+  void* d_tile = nullptr; size_t cap_tile = 0;   // rt_render_multi: this handle's rows before they are copied into the frame
   HitRec* d_hits = nullptr;
   // large scenes: hits of level >= 1 are regrouped by grid cell before shading (rt_sort.hpp)
   bool sort_hits = false; SortGrid sort_grid{};
@@ -545,6 +546,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) try {
   if (s->d_lights) hipFree(s->d_lights);
   if (s->d_nodes) hipFree(s->d_nodes);
   if (s->d_pbound) hipFree(s->d_pbound);
+  if (s->d_tile) hipFree(s->d_tile);
   if (s->d_hpair) hipFree(s->d_hpair);
   if (s->d_haxis) hipFree(s->d_haxis);
   if (s->d_hleaf) hipFree(s->d_hleaf);
@@ -1303,6 +1305,95 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
 
 // Pinned host memory for output frames (hipHostMalloc): device -> host copies into it run at PCIe speed and
 // asynchronously; into pageable memory they are staged by the runtime at a fraction of that.
+// ------------------------------------------------------------------ rt_render_multi -----------
+extern "C" int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_camera* camera, const rt_frame* frame, void* out,
+                               int out_is_device, rt_stats* stats) try {
+  if (!scenes || n_scenes < 1 || !camera || !frame || !out) return fail(RT_ERR_INVALID, "rt_render_multi: null pointer or no scenes");
+  if (n_scenes > 64) return fail(RT_ERR_INVALID, "rt_render_multi: at most 64 handles");
+  for (int i = 0; i < n_scenes; ++i) if (!scenes[i]) return fail(RT_ERR_INVALID, "rt_render_multi: scenes[%d] is null", i);
+  if (frame->jitter_mode != RT_JITTER_PIXEL_KEYED) return fail(RT_ERR_INVALID, "rt_render_multi: pixel-keyed jitter only (the numpy stream is consumed frame-wide)");
+  if (frame->block_rows <= 0 || frame->width <= 0 || frame->height <= 0) return fail(RT_ERR_INVALID, "rt_render_multi: bad frame size / block_rows");
+  const size_t esz = frame->out_format == RT_OUT_F64 ? 8 : (frame->out_format == RT_OUT_F32 ? 4 : 1);
+  const size_t row_bytes = (size_t)frame->width * 3 * esz, block_bytes = row_bytes * (size_t)frame->block_rows;
+  std::vector<rt_stats> st((size_t)n_scenes);
+  std::vector<int32_t> rows((size_t)n_scenes, 0);
+  std::vector<rt_frame> fr((size_t)n_scenes, *frame);
+  // 1. every handle renders its rows into its own tile buffer, all at once
+  for (int i = 0; i < n_scenes; ++i) {
+    rt_scene* s = scenes[i];
+    fr[i].part = i; fr[i].n_parts = n_scenes; fr[i].flags = (frame->flags | RT_FLAG_ASYNC) & ~RT_FLAG_TIMING;
+    int rc = rt_rows_in_part(frame->height, frame->block_rows, i, n_scenes, &rows[i]);
+    if (rc != RT_OK) return rc;
+    if (rows[i] == 0) continue;
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      HIPCHK(hipSetDevice(s->device));
+      const size_t need = (size_t)rows[i] * row_bytes;
+      if (need > s->cap_tile) {
+        rc = drain(s); if (rc == RT_ERR_QUEUE_OVERFLOW) s->sticky_overflow = 1; else if (rc != RT_OK) return rc;
+        if (s->d_tile) hipFree(s->d_tile);
+        s->d_tile = nullptr; s->cap_tile = 0;
+        HIPCHK(hipMalloc(&s->d_tile, need));
+        s->cap_tile = need;
+      }
+    }
+    rc = rt_render(s, camera, &fr[i], s->d_tile, 1, &st[i]);
+    if (rc != RT_OK) return rc;
+  }
+  // 2. completion; a handle whose queues overflowed renders again, blocking (rt_render grows the queues and retries)
+  for (int i = 0; i < n_scenes; ++i) {
+    if (rows[i] == 0) continue;
+    int rc = rt_sync(scenes[i]);
+    if (rc == RT_ERR_QUEUE_OVERFLOW) { fr[i].flags &= ~RT_FLAG_ASYNC; rc = rt_render(scenes[i], camera, &fr[i], scenes[i]->d_tile, 1, &st[i]); }
+    if (rc != RT_OK) return rc;
+  }
+  // 3. every device copies its row blocks into the frame: block b of handle i is block b*n + i of the frame
+  const int dst_device = scenes[0]->device;
+  for (int i = 0; i < n_scenes; ++i) {
+    if (rows[i] == 0) continue;
+    rt_scene* s = scenes[i];
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    if (out_is_device && s->device != dst_device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, s->device, dst_device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(RT_ERR_HIP, "peer access %d -> %d: %s", s->device, dst_device, hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+    }
+    const int32_t full = rows[i] / frame->block_rows, tail = rows[i] - full * frame->block_rows;
+    char* dst0 = (char*)out + (size_t)i * block_bytes;
+    if (full > 0)
+      HIPCHK(hipMemcpy2DAsync(dst0, (size_t)n_scenes * block_bytes, s->d_tile, block_bytes, block_bytes, (size_t)full,
+                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->stream));
+    if (tail > 0)     // the frame's last, short block
+      HIPCHK(hipMemcpyAsync(dst0 + (size_t)full * n_scenes * block_bytes, (char*)s->d_tile + (size_t)full * block_bytes, (size_t)tail * row_bytes,
+                            out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->stream));
+  }
+  for (int i = 0; i < n_scenes; ++i) {
+    if (rows[i] == 0) continue;
+    HIPCHK(hipSetDevice(scenes[i]->device));
+    HIPCHK(hipStreamSynchronize(scenes[i]->stream));
+  }
+  HIPCHK(hipSetDevice(dst_device));
+  if (stats) {
+    rt_stats t; std::memset(&t, 0, sizeof t);
+    t.levels = frame->max_depth + 1;
+    for (int i = 0; i < n_scenes; ++i) {
+      if (rows[i] == 0) continue;
+      const rt_stats& b = st[i];
+      t.rays += b.rays; t.hits += b.hits; t.shadow_rays += b.shadow_rays; t.retested += b.retested;
+      t.segments = (b.segments < 0 || t.segments < 0) ? -1 : t.segments + b.segments;
+      for (int l = 0; l < t.levels && l < RT_MAX_LEVELS; ++l) { t.level_rays[l] += b.level_rays[l]; t.level_hits[l] += b.level_hits[l]; }
+      t.trace_launches += b.trace_launches; t.shade_launches += b.shade_launches;
+    }
+    for (int l = 0; l < t.levels && l < RT_MAX_LEVELS; ++l) if (t.level_rays[l]) t.batches++;
+    *stats = t;
+  }
+  return RT_OK;
+} RT_CATCH_ALL
+
 extern "C" int rt_host_alloc(size_t bytes, void** out) try {
   if (!out) return fail(RT_ERR_INVALID, "rt_host_alloc: null pointer");
   *out = nullptr;

@@ -250,6 +250,38 @@ def render_hip(camera, scene_settings, materials, surfaces, lights, width, heigh
 render_vectorized = render_hip   # same name as the reference entry point
 
 
+def render_multi(scenes, camera, width, height, n_shadow, max_depth, *, precision="fp32", jitter=None, block_rows=8,
+                 out_format=None, out_ptr=None, out=None, flags=0):
+    """ONE frame rendered by several GpuScene handles (the same scene, one per GPU) through rt_render_multi: handle i
+    renders the interleaved row blocks i, i + n, ... and copies them straight into the frame.  Returns (image, stats);
+    with `out_ptr` (device memory on scenes[0]'s GPU) the image is None."""
+    jit = as_jitter(jitter)
+    if camera.forward is None:
+        camera.setup(width / height)
+    cam = _lib.CameraDesc()
+    v = pack_camera(camera)
+    cam.pos[:] = v[0:3]; cam.forward[:] = v[3:6]; cam.right[:] = v[6:9]; cam.up[:] = v[9:12]
+    cam.screen_distance, cam.screen_width, cam.screen_height = v[12], v[13], v[14]
+    prec = _PRECISION[precision]
+    if out_format is None:
+        out_format = "f64" if prec == _lib.RT_FP64 else "f32"
+    fmt, dtype = _OUT[out_format]
+    fr = _lib.Frame(int(width), int(height), int(block_rows), 0, 1, int(n_shadow), int(max_depth), prec, int(jit.mode),
+                    jit.seed & 0xFFFFFFFF, fmt, int(flags))
+    handles = (C.c_void_p * len(scenes))(*[gs._h for gs in scenes])
+    st = _lib.Stats()
+    lib = _lib.load()
+    if out_ptr is not None:
+        _lib.check(lib.rt_render_multi(handles, len(scenes), C.byref(cam), C.byref(fr), C.c_void_p(out_ptr), 1, C.byref(st)))
+        return None, st.as_dict()
+    if out is None:
+        out = pinned.empty((height, width, 3), dtype)
+    elif out.shape != (height, width, 3) or out.dtype != dtype or not out.flags.c_contiguous:
+        raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of shape {(height, width, 3)}")
+    _lib.check(lib.rt_render_multi(handles, len(scenes), C.byref(cam), C.byref(fr), _ptr(out), 0, C.byref(st)))
+    return out, st.as_dict()
+
+
 def render(camera, scene_settings, materials, surfaces, lights, width, height, **kw):
     """Counterpart of the reference's sequential `render` (ray_tracer.py:398-434) on the GPU."""
     return render_hip(camera, scene_settings, materials, surfaces, lights, width, height, sequential=True, **kw)

@@ -1,0 +1,70 @@
+"""rt_render_multi (the multi-GPU boundary for callers without torch.distributed): one frame rendered by
+several scene handles, interleaved row blocks, each handle copying its blocks straight into the frame.  One GPU is
+enough to check the tiling, the strided copies (incl. a short last block) and the summed counters: the handles then
+share the device.  On a multi-GPU box the same call spreads over the devices the handles were created on."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import rel_err, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _q(img):
+    from raytracer_amd.image import quantize_u8
+    return quantize_u8(img).astype(int)
+
+
+@pytest.mark.parametrize("n_handles,W,H,block_rows", [(3, 96, 70, 8), (2, 80, 48, 8), (4, 64, 37, 4), (5, 33, 9, 8)])
+def test_multi_equals_single_fp64(oracle, n_handles, W, H, block_rows):
+    from raytracer_amd import load_scene
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene, render_multi
+    cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"), 2, 3)
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    scenes = [GpuScene(packed) for _ in range(n_handles)]
+    try:
+        single = scenes[0].render(cam, W, H, 2, 3, precision="fp64", jitter=11)
+        s1 = dict(scenes[0].last_stats)
+        img, sm = render_multi(scenes, cam, W, H, 2, 3, precision="fp64", jitter=11, block_rows=block_rows)
+        assert img.shape == (H, W, 3) and img.dtype == np.float64
+        assert rel_err(img, single).max() < 1e-12           # (accumulation order of a pixel's child rays only)
+        for k in ("rays", "hits", "shadow_rays", "segments", "level_rays", "level_hits"):
+            assert sm[k] == s1[k], k
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 11))
+        assert rel_err(img, ref).max() < 1e-9
+    finally:
+        for gs in scenes:
+            gs.close()
+
+
+def test_multi_device_output_fp32_and_u8(oracle):
+    from raytracer_amd import load_scene
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene, render_multi
+    W, H = 160, 100
+    cam, st, mats, surfs, lights = load_scene(scene_path("pool.txt"), 3, 2)
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 5))
+    hip = ctypes.CDLL("libamdhip64.so")
+    scenes = [GpuScene(packed) for _ in range(3)]
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), W * H * 3 * 4) == 0
+    try:
+        _, sm = render_multi(scenes, cam, W, H, 3, 2, precision="fp32", jitter=5, out_ptr=buf.value)
+        out = np.empty((H, W, 3), dtype=np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), buf, out.nbytes, 2) == 0
+        assert np.abs(_q(out) - _q(ref)).max() <= 1
+        u8, _ = render_multi(scenes, cam, W, H, 3, 2, precision="fp32", jitter=5, out_format="u8")
+        assert u8.dtype == np.uint8 and np.abs(u8.astype(int) - _q(ref)).max() <= 1
+        single = scenes[0].render(cam, W, H, 3, 2, precision="fp32", jitter=5)
+        assert sm["rays"] == scenes[0].last_stats["rays"] and sm["shadow_rays"] == scenes[0].last_stats["shadow_rays"]
+        assert np.abs(out - single).max() < 2e-5
+    finally:
+        hip.hipFree(buf)
+        for gs in scenes:
+            gs.close()
