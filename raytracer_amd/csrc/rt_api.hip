@@ -664,6 +664,16 @@ static int drain(rt_scene* s) {
                         (double)w[0] / w[5], (double)w[1] / w[5], (double)w[2] / w[5], (double)w[3] / w[5], (double)w[4] / w[5], w[5], w[6]);
     }
 #endif
+#ifdef RT_DEBUG_KERNEL
+    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 23))) {
+      unsigned long long w[8] = {0}, z[8] = {0};
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_fix_cause), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_fix_cause), z, sizeof z);
+      fprintf(stderr, "[rt debug] k_shade_ls re-test causes: %llu pairs; light's sample square touches a candidate %llu; of the rest (a pair can have several): "
+              "grazing discriminant %llu, root at the shadow origin %llu, parallel to a plane %llu, light within 3 radii %llu, far hit %llu\n",
+              w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+    }
+#endif
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))
       fprintf(stderr, "[rt debug] k_shade_ls (wave, light) pairs: %llu total, %llu without a sample loop\n",
               (unsigned long long)(c.queries >> 32), (unsigned long long)(c.queries & 0xFFFFFFFFull));

@@ -73,6 +73,7 @@ struct LsPrims {
   v2f (&Cc)[MAXS];                             // (C, cc) = (oc.up, |oc|^2 - r^2)
   v2f (&Sg)[(MAXS + 1) / 2];                   // root signs of spheres (2j, 2j+1): +1 far root (origin inside), -1 near root
   const float (&tauS)[MAXS];
+  const float (&kapS)[MAXS];                   // per (hit, light, sphere): error bound of the discriminant per unit of |oc.ts| (LsTol::kap with THIS sphere's |oc|)
   v2f (&D01)[MAXP]; v2f (&D2n)[MAXP];          // (N.tl, N.right), (N.up, offset - p.N)
   const float (&tauP)[MAXP];
   const float (&blo)[MAXB > 0 ? MAXB : 1][3]; const float (&bhi)[MAXB > 0 ? MAXB : 1][3];
@@ -122,11 +123,11 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
   uint32_t mlow = fl.mlow;
   // LO: coefficients of the lane's OWN sphere (selected once; the slow path is rare and must not
   // raise the kernel's register budget, so only the own sphere gets the two-root treatment)
-  float oA = 0.0f, oB = 0.0f, oC = 0.0f, occ = 1.0f, otau = 1.0f;
+  float oA = 0.0f, oB = 0.0f, oC = 0.0f, occ = 1.0f, otau = 1.0f, okap = kap;
   if (LO) {
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (own == k) { oA = AB[k].x; oB = AB[k].y; oC = Cc[k].x; occ = Cc[k].y; if (!OPAQUE) otau = pr.tauS[k]; }
+      if (own == k) { oA = AB[k].x; oB = AB[k].y; oC = Cc[k].x; occ = Cc[k].y; okap = pr.kapS[k]; if (!OPAQUE) otau = pr.tauS[k]; }
   }
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
@@ -163,7 +164,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
       const v2f sq = pk_sqrt(disc);                                                              // NaN on a miss
       const v2f sg = (k & 1) ? hi2(Sg[k >> 1]) : lo2(Sg[k >> 1]);
       // a discriminant within its error bound of zero: the sample grazes the silhouette
-      unc = fmaxf(unc, fmaxf(fmaf(kap, fabsf(bt.x), -fabsf(disc.x)), fmaf(kap, fabsf(bt.y), -fabsf(disc.y))));
+      unc = fmaxf(unc, fmaxf(fmaf(pr.kapS[k], fabsf(bt.x), -fabsf(disc.x)), fmaf(pr.kapS[k], fabsf(bt.y), -fabsf(disc.y))));
       if (LO) {                                                             // own sphere: handled after the loop
         if (OPAQUE) {
           v2f u = pk_fma(sg, sq, -bt);
@@ -209,7 +210,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
         const bool nr = (fabsf(s1.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s1.y - lo2_.y) <= 1e-3f * lo2_.y) |
                         (fabsf(s2.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s2.y - lo2_.y) <= 1e-3f * lo2_.y);
         unc = nr ? 3.0e38f : unc;
-        unc = fmaxf(unc, fmaxf(fmaf(kap, fabsf(bt.x), -fabsf(disc.x)), fmaf(kap, fabsf(bt.y), -fabsf(disc.y))));
+        unc = fmaxf(unc, fmaxf(fmaf(okap, fabsf(bt.x), -fabsf(disc.x)), fmaf(okap, fabsf(bt.y), -fabsf(disc.y))));
       }
       if (OPAQUE) {
         m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1;                 // 0 = "blocked" for the final compare
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     float a_tauP[MAXP];
     float a_blo[MAXB > 0 ? MAXB : 1][3], a_bhi[MAXB > 0 ? MAXB : 1][3], a_tauB[MAXB > 0 ? MAXB : 1];
     bool a_binside[MAXB > 0 ? MAXB : 1];
-    LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_AB, a_Cc, a_Sg, a_tauS, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
+    float a_kapS[MAXS];
+    LsPrims<MAXS, MAXP, MAXB, OPAQUE> pr{a_AB, a_Cc, a_Sg, a_tauS, a_kapS, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
     d3 p = mk3(0, 0, 0);
     f3 pf = mkf(0, 0, 0), pl = mkf(0, 0, 0);
     f3 nf = mkf(0, 0, 1), v = mkf(0, 0, 1), wgt = mkf(0, 0, 0);
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float2* cells = s_cells + li * n_cells;
       float total;
       bool undecided = false;      // this (hit, light) goes to the exact re-test (k_fix_exact) with T = 0 here
+      uint32_t dbg_cause = 0u;
       if (RT_DBG(fp) & 8u) act = 0xFFFFFFFFu;
       uint32_t str_act = act & s_lstr[li];
       if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
@@ -751,6 +754,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const float tsm = tlen + RL;
         const float e_b = 1.5f * LS_U * ocm * (9.0f * tsm + 25.0f * RL);
         tol.kap = 2.0f * e_b + 51.0f * LS_U * ocm * tsm;
+        {
+          // the same bound with each sphere's own |oc| = sqrt(cc + r^2) instead of the largest one (a grazed sphere is
+          // usually a near one: 3-5x fewer undecided pairs on the pool scene), never below 1e-3 of it
+          const float kap1 = tol.kap * raw_rcp(fmaxf(ocm, 1e-30f));
+#pragma unroll
+          for (int k = 0; k < MAXS; ++k) {
+            a_kapS[k] = tol.kap;
+            if (act & (1u << k)) {
+              const float r_ = s_sphf[k].w;
+              const float ock = raw_sqrt(fmaxf(fmaf(r_, r_, a_Cc[k].y), 0.0f)) * 1.0001f + 1e-3f * ocm;
+              a_kapS[k] = fminf(kap1 * ock, tol.kap);
+            }
+          }
+        }
         tol.kap0 = 2.0f * e_b * e_b;
         tol.elo = 2.0f * T_LO * tsm + 2.0f * (e_b + tol.kap);
         tol.eden = 12.0f * LS_U * tsm;
@@ -766,6 +783,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
         const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
         undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far;
+        if (RT_DBG(fp) & (1u << 23))    // cause bits: 1 grazing discriminant, 2 root at the origin, 4 parallel plane, 8 light close, 16 far
+          dbg_cause = (!(fl.unc < -tol.kap0) ? 1u : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
+                      (((T0 < 9.0f * RL * RL) | !(T0 > 1e-12f)) ? 8u : 0u) | (far ? 16u : 0u);
       }
       if (prof) { const long long t = clock64(); ck_loop += t - ck_t; ck_t = t; }
       if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
@@ -780,6 +800,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       if (!lane_can) { total = (float)n_cells; undecided = false; }
       if (OPAQUE && lane_full) { total = 0.0f; undecided = false; }
       undecided &= active;
+      if ((RT_DBG(fp) & (1u << 23)) && undecided) {      // audit build: why pairs go to the re-test queue
+#ifdef RT_DEBUG_KERNEL
+        atomicAdd(&g_fix_cause[0], 1ull);
+        if (str_act != 0u) atomicAdd(&g_fix_cause[1], 1ull);
+        for (int b_ = 0; b_ < 5; ++b_) if (dbg_cause & (1u << b_)) atomicAdd(&g_fix_cause[2 + b_], 1ull);
+#endif
+      }
       if (undecided) total = 0.0f;
       const float T = total * inv_cells;
       const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
