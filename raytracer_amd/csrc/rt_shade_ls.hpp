@@ -615,54 +615,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
-      bool sw = fabsf(ld.x) >= 0.9f;
-      if (__any(active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))) {             // within rounding of the switch: decide it in fp64
-        const uint32_t t_ = threadIdx.x;
-        if (active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))
-          sw = basis_switch_exact(sc, mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS), li);
-      }
-      const f3 ref = sw ? mkf(0, 1, 0) : mkf(1, 0, 0);
-      const f3 right = normalize_clamped(crossf(ld, ref));
-      const f3 up = normalize_clamped(crossf(right, ld));
-      const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
       const float radius = lg[8];
-      const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
-      const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+      const float nt = dotf(nf, tl);
       const uint32_t wcan = (nS * sc.nL <= 64 && !brute) ? (uint32_t)(pair_can >> (li * nS)) : 0xFFFFFFFFu;   // spheres this wave may touch
-#pragma unroll
-      for (int k = 0; k < MAXS; ++k) {
-        a_AB[k] = mk2(0.0f, 0.0f); a_Cc[k].x = 0.0f;
-        if (k < nS && ((wcan >> k) & 1u)) {
-          const float4 sf = s_sphf[k], sl = s_sphl[k];
-          const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
-          a_AB[k] = mk2(dotf(oc, tl), dotf(oc, right)); a_Cc[k].x = dotf(oc, up);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < MAXP; ++k) {
-        a_D01[k] = mk2(0.0f, 0.0f); a_D2n[k].x = 0.0f;
-        if (k < nP) {
-          const Prim& s_ = P[nS + k];
-          const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
-          a_D01[k] = mk2(dotf(N, tl), dotf(N, right)); a_D2n[k].x = dotf(N, up);
-        }
-      }
+      float total = (float)n_cells;
+      bool undecided = false;      // this (hit, light) goes to the exact re-test (k_fix_exact) with T = 0 here
+      uint32_t dbg_cause = 0u, str_act = 0u;
+      bool lane_can = false;     // some primitive may cross some shadow segment of this lane
+      bool lane_full = false;    // opaque scenes: one sphere certainly blocks EVERY sample of this lane
+      // ---- phase A: conservative per-(wave, light) culling, WITHOUT the light's basis.  A primitive is tested only if
+      // it can cross the shadow segment of SOME sample of this light for SOME lane of the wave (results unchanged).
+      // Every sample lies within RL of the light centre, so the segment p -> sample stays within RL of the segment
+      // p -> Lp.  Only oc.tl, N.tl and per-hit terms enter; where the basis-dependent coefficients B = oc.right,
+      // C = oc.up (D1, D2 for planes) used to, their bound |B| + |C| <= sqrt2 |oc - (oc.ld) ld| does.  60 % of the
+      // (wave, light) pairs of the pool frame end here (every lane fully lit or in an umbra) and never need the
+      // basis, the jitter key, B, C, D1, D2 or the error bounds.
       // Slow path (exact lower bound 2e-6 on every crossing) only if some lane needs it: the light is
       // (partly) behind the hit's own surface AND the outcome can depend on the own-surface crossing the
       // reference does not see — always for an own plane and in scenes with transparency; in all-opaque
       // scenes an own sphere / box blocks through its far side anyway unless the light is on its other side.
-      const float nt = dotf(nf, tl);
       const bool behind = nt < 0.71f * radius;
       // the hit point and (some sample of) the light possibly on different sides of the hit's own sphere /
       // box: then the only crossing between them is the one at the hit point itself
       bool own_light_inside = ((own_out_bit & s_lin[li]) | (own_in_bit & s_lout[li])) != 0u;
-      // Conservative per-(wave, light) culling: a primitive is tested only if it can cross the
-      // shadow segment of SOME sample of this light for SOME lane of the wave (results unchanged).
-      // Every sample lies within RL of the light centre, so the segment p -> sample stays within RL
-      // of the segment p -> Lp.
       uint32_t act = 0;
-      bool lane_can = false;     // some primitive may cross some shadow segment of this lane
-      bool lane_full = false;    // opaque scenes: one sphere certainly blocks EVERY sample of this lane
       const float RL = 0.7072f * radius * 1.001f;
       {
         // Sphere k can cross the segment p -> S of some sample S only if, for some tau in [0,1],
@@ -670,18 +646,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // p -> Lp):  g(tau) = tau^2 (T0 - RL^2) + 2 tau (A - r RL) + cc <= 0, minimised on [0,1].
         const float qa = T0 - RL * RL, rqa = raw_rcp(qa);
         const float rT0 = rl * rl;                                             // 1 / |tl|^2
-        const float hw = 0.5005f * radius;                                    // |oi|, |oj| <= radius / 2
+        const float hw2 = 0.5005f * radius * 1.4143f;                         // |oi|, |oj| <= radius / 2; |B| + |C| <= sqrt2 sqrt(B^2 + C^2)
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
+          a_AB[k] = mk2(0.0f, 0.0f); a_Cc[k].x = 0.0f;
           if (k < nS && ((wcan >> k) & 1u)) {
-            const float r = s_sphf[k].w;
-            const float A_ = a_AB[k].x, B_ = a_AB[k].y, C_ = a_Cc[k].x, cc_ = a_Cc[k].y;
+            const float4 sf = s_sphf[k], sl = s_sphl[k];
+            const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
+            const float A_ = dotf(oc, tl), cc_ = a_Cc[k].y, r = sf.w;
+            a_AB[k].x = A_;
             const float qb = A_ - r * RL;
             const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
             const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), cc_);
             // origin outside the sphere and every sample direction leaves it (oc.ts > 0 for all samples):
-            // both roots are <= 0 — the lit side of the hit's own sphere, spheres behind the hit
-            const float bt_lo = A_ - hw * (fabsf(B_) + fabsf(C_));
+            // both roots are <= 0 — the lit side of the hit's own sphere, spheres behind the hit.
+            // B^2 + C^2 = |oc|^2 - (oc.ld)^2 = cc + r^2 - A^2 / |tl|^2  (+ 0.1 % and a few ulp of |oc|^2 for its rounding)
+            const float oc2 = fmaf(r, r, cc_);
+            const float perp2 = fmaxf(fmaf(-A_ * rT0, A_, oc2) * 1.001f + 1e-6f * oc2, 0.0f);
+            const float bt_lo = fmaf(-hw2, raw_sqrt(perp2), A_);
             const bool away = (cc_ >= 0.0f) & (bt_lo > 1e-5f * (fabsf(A_) + 1e-3f));
             const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc_) + r * r))) & !away;
             lane_can |= can;
@@ -714,9 +696,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         lane_full &= !own_light_inside;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
+          a_D01[k] = mk2(0.0f, 0.0f); a_D2n[k].x = 0.0f;
           if (k < nP) {
-            const float D0_ = a_D01[k].x, num_ = a_D2n[k].y;
-            const float spread = hw * (fabsf(a_D01[k].y) + fabsf(a_D2n[k].x)) + 1e-6f * fabsf(D0_);
+            const Prim& s_ = P[nS + k];
+            const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+            const float D0_ = dotf(N, tl), num_ = a_D2n[k].y;
+            a_D01[k].x = D0_;
+            // |N.right| + |N.up| <= sqrt2 |N - (N.ld) ld|, N unit (to 0.1 %)
+            const float nperp2 = fmaxf(fmaf(-D0_ * rT0, D0_, 1.002f), 0.0f);
+            const float spread = hw2 * raw_sqrt(nperp2) + 1e-6f * fabsf(D0_);
             // tau = num / den in (0, 1) needs num and den of the same sign
             const bool can = num_ < 0.0f ? (D0_ - spread <= 0.0f) : (num_ > 0.0f ? (D0_ + spread >= 0.0f) : true);
             lane_can |= can;
@@ -726,20 +714,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         if (MAXB > 0) lane_can |= nB > 0;
       }
       if (brute) { act = all_prims; lane_can = true; lane_full = false; }
-      if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
-      const float2* cells = s_cells + li * n_cells;
-      float total;
-      bool undecided = false;      // this (hit, light) goes to the exact re-test (k_fix_exact) with T = 0 here
-      uint32_t dbg_cause = 0u;
       if (RT_DBG(fp) & 8u) act = 0xFFFFFFFFu;
-      uint32_t str_act = act & s_lstr[li];
-      if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
       if (!brute && !(RT_DBG(fp) & 2u) && !__any(active & lane_can & !lane_full)) {
         // No lane of the wave has a penumbra candidate for this light: every lane is either fully lit
         // (all n^2 terms are exactly 1) or in the umbra of one opaque sphere (all terms exactly 0).
         total = lane_full ? 0.0f : (float)n_cells;
         if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull);
-      } else if (str_act != 0u) {
+        if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
+      } else {
+      // ---- phase B: the light's basis and what depends on it, for the primitives phase A left
+      bool sw = fabsf(ld.x) >= 0.9f;
+      if (__any(active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))) {             // within rounding of the switch: decide it in fp64
+        const uint32_t t_ = threadIdx.x;
+        if (active & (fabsf(fabsf(ld.x) - 0.9f) < 1e-5f))
+          sw = basis_switch_exact(sc, mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS), li);
+      }
+      const f3 ref = sw ? mkf(0, 1, 0) : mkf(1, 0, 0);
+      const f3 right = normalize_clamped(crossf(ld, ref));
+      const f3 up = normalize_clamped(crossf(right, ld));
+      const float T1 = 2.0f * dotf(tl, right), T2 = 2.0f * dotf(tl, up);
+      const float cell32 = n_sh > 1 ? (radius / (float)n_side) * JIT_SCALE : 0.0f;
+      const JitKey key = jit_light_key(fp.seed, gpix, (uint32_t)level, (uint32_t)li);
+      const bool lo_path = (RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true));
+      // (the slow path reads the coefficients of each lane's OWN sphere, whether or not the wave tests that sphere)
+      const uint32_t bc_mask = lo_path ? (wcan | act) : act;
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k) {
+        if (k < nS && ((bc_mask >> k) & 1u)) {
+          const float4 sf = s_sphf[k], sl = s_sphl[k];
+          const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
+          a_AB[k].y = dotf(oc, right); a_Cc[k].x = dotf(oc, up);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        if (k < nP && ((act >> (16 + k)) & 1u)) {
+          const Prim& s_ = P[nS + k];
+          const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+          a_D01[k].y = dotf(N, right); a_D2n[k].x = dotf(N, up);
+        }
+      }
+      if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
+      const float2* cells = s_cells + li * n_cells;
+      str_act = act & s_lstr[li];
+      if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
+      if (str_act != 0u) {
         // the light's sample square touches a candidate primitive: crossings at the sample end of a segment
         total = 0.0f; undecided = true;
       } else {
@@ -772,7 +791,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         tol.elo = 2.0f * T_LO * tsm + 2.0f * (e_b + tol.kap);
         tol.eden = 12.0f * LS_U * tsm;
         LsFlags fl = ls_flags_init();
-        if ((RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true)))
+        if (lo_path)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                      T0, T1, T2, tol.kap, fl, own);
         else
@@ -787,6 +806,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
           dbg_cause = (!(fl.unc < -tol.kap0) ? 1u : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
                       (((T0 < 9.0f * RL * RL) | !(T0 > 1e-12f)) ? 8u : 0u) | (far ? 16u : 0u);
       }
+      }   // phase B
       if (prof) { const long long t = clock64(); ck_loop += t - ck_t; ck_t = t; }
       if ((RT_DBG(fp) & 1u) && lane == 0) atomicAdd(&C->queries, 1ull << 32);
       if ((RT_DBG(fp) & 2u) && active) {      // shortcut disabled: audit what it would have claimed
