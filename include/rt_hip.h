@@ -121,9 +121,13 @@ int rt_device_count(int* count);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
-/* Use an external HIP stream (a hipStream_t, e.g. torch's current stream) for every later call on
- * this scene; NULL restores the scene's own stream. */
+/* Use an external HIP stream (a hipStream_t, e.g. a torch.cuda.Stream's) for every later call on
+ * this scene; NULL restores the scene's own stream, a private NON-BLOCKING stream (so NULL does not mean
+ * the legacy default stream: work on it is not ordered with the caller's default-stream work). */
 int rt_scene_set_stream(rt_scene* scene, void* hip_stream);
+/* Wait for every RT_FLAG_ASYNC frame of the scene, fill their rt_stats.  Returns RT_ERR_QUEUE_OVERFLOW when one
+ * of them — since the last rt_sync — overflowed its bounce queues (its image is incomplete; the queues have been
+ * grown for the frames that follow: render it again). */
 int rt_sync(rt_scene* scene);
 
 /* Number of rows in a row set (host arithmetic only). */
