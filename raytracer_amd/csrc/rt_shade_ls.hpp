@@ -794,7 +794,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         if (lo_path)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                      T0, T1, T2, tol.kap, fl, own);
-        else
+        else if (MAXS > 2 && __popc(act & ((1u << MAXS) - 1u)) <= 2) {
+          // At most two spheres left for this (wave, light) — the usual case: their coefficients are moved to two
+          // dense slots (wave-uniform moves), and the sample loop runs in its two-sphere instantiation: per sample pair
+          // it then tests 2 instead of MAXS "is this sphere active" bits on the scalar unit (each a compare + branch).
+          v2f gAB[2], gCc[2], gSg[1];
+          float gtau[2], gkap[2];
+          gAB[0] = gAB[1] = mk2(0.0f, 0.0f); gCc[0] = gCc[1] = mk2(0.0f, 1.0f); gSg[0] = mk2(-1.0f, -1.0f);
+          gtau[0] = gtau[1] = 0.0f; gkap[0] = gkap[1] = 0.0f;
+          int j = 0;
+#pragma unroll
+          for (int k = 0; k < MAXS; ++k) {
+            if ((act >> k) & 1u) {
+              const float sg_ = (k & 1) ? a_Sg[k >> 1].y : a_Sg[k >> 1].x;
+              if (j == 0) { gAB[0] = a_AB[k]; gCc[0] = a_Cc[k]; gSg[0].x = sg_; gtau[0] = a_tauS[k]; gkap[0] = a_kapS[k]; }
+              else        { gAB[1] = a_AB[k]; gCc[1] = a_Cc[k]; gSg[0].y = sg_; gtau[1] = a_tauS[k]; gkap[1] = a_kapS[k]; }
+              ++j;
+            }
+          }
+          LsPrims<2, MAXP, MAXB, OPAQUE> pr2{gAB, gCc, gSg, gtau, gkap, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
+          const uint32_t act2 = (act & ~((1u << MAXS) - 1u)) | ((1u << j) - 1u);
+          total = ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up,
+                                                                T0, T1, T2, tol.kap, fl);
+        } else
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                       T0, T1, T2, tol.kap, fl);
         // also undecided in fp32: the light within 3 sample-square radii of the hit (|ts| is then not comparable
