@@ -104,12 +104,16 @@ __device__ __forceinline__ bool ls_decided(const LsFlags& f, const LsTol& t) {
 // stream (measured: 170 SALU vs 134 VALU instructions per pair).
 // NS = MAXS: the kernel is instantiated for sphere counts 2, 4, 6; unused slots hold A = B = C = 0,
 // cc = 1 (negative discriminant, never hit), so the sphere loop has no guards.
-template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool LO>
+// SDENSE: every one of the NS sphere slots is active (no per-slot test of `act`); NOPLANES: no plane is active (the plane
+// block is compiled out).  Both are wave-uniform facts of a (wave, light) pair, known before the loop: tested once there
+// instead of once per sample pair on the scalar unit (a compare + branch each, measured 3-5 % of the frame).
+template <int NS, int MAXS, int MAXP, int MAXB, bool OPAQUE, bool LO, bool SDENSE = false, bool NOPLANES = false>
 __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>& pr, uint32_t act, int nB,
-                                              const float2* __restrict__ cells, int n_cells, JitKey key, float cell32,
+                                              const float4* __restrict__ cells, int n_cells, JitKey key, float cell32,
                                               f3 tl, f3 right, f3 up, float T0, float T1, float T2, float kap,
                                               LsFlags& fl, int own = -1) {
   float total = 0.0f;
+  uint32_t n_blocked = 0u;
   const int n_pairs = (n_cells + 1) >> 1;
   // The coefficient pairs pass through an empty asm statement in every iteration (values unchanged): that makes
   // them loop-variant for the optimiser, so the broadcasts lo2() / hi2() stay inside the loop body, where
@@ -131,7 +135,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
   }
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
-  float2 nb0 = cells[0], nb1 = cells[n_cells > 1 ? 1 : 0];
+  float4 nb = cells[0];                                                     // (b0.x, b1.x, b0.y, b1.y) of sample pair 0
   uint32_t xa = key.a + JIT_PHI_A, xb = key.b + JIT_PHI_B;                  // cell 0 (see jit_ui / jit_uj)
 #pragma unroll 1
   for (int q = 0; q < n_pairs; ++q) {
@@ -143,14 +147,11 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     for (int k = 0; k < MAXP; ++k) { asm("" : "+v"(D01[k])); asm("" : "+v"(D2n[k])); }
     const int c0 = 2 * q, c1 = 2 * q + 1;
     const bool valid1 = c1 < n_cells;                                       // wave-uniform
-    const float2 b0 = nb0, b1 = nb1;
-    {
-      const int p0 = c0 + 2 < n_cells ? c0 + 2 : 0, p1 = c1 + 2 < n_cells ? c1 + 2 : 0;
-      nb0 = cells[p0]; nb1 = cells[p1];
-    }
+    const float4 bq = nb;
+    nb = cells[q + 1 < n_pairs ? q + 1 : 0];
     v2f oi, oj;                                                             // ray_tracer.py:224-225
-    oi.x = fmaf((float)xa, cell32, b0.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, b1.x);
-    oj.x = fmaf((float)xb, cell32, b0.y); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, b1.y);
+    oi.x = fmaf((float)xa, cell32, bq.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, bq.y);
+    oj.x = fmaf((float)xb, cell32, bq.z); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, bq.w);
     xa += 2u * JIT_PHI_A; xb += 2u * JIT_PHI_B;                             // jitter lattice of the next pair
     const v2f d2 = pk_fma(oi, splat(T1) + oi, pk_fma(oj, splat(T2) + oj, splat(T0)));   // |ts|^2
     uint32_t m0 = 0xFFFFFFFFu, m1 = valid1 ? 0xFFFFFFFFu : 0u;             // min of candidate bit patterns
@@ -158,13 +159,13 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     v2f tr = splat(1.0f);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {                                          // spheres: sphere.py:49-71
-      if (!(act & (1u << k))) continue;                                     // culled for this (wave, light)
+      if (!SDENSE && !(act & (1u << k))) continue;                          // culled for this (wave, light)
       const v2f bt = pk_fma(oj, lo2(Cc[k]), pk_fma(oi, hi2(AB[k]), lo2(AB[k])));                 // oc.ts
       const v2f disc = pk_fma(bt, bt, -(d2 * hi2(Cc[k])));
       const v2f sq = pk_sqrt(disc);                                                              // NaN on a miss
       const v2f sg = (k & 1) ? hi2(Sg[k >> 1]) : lo2(Sg[k >> 1]);
       // a discriminant within its error bound of zero: the sample grazes the silhouette
-      unc = fmaxf(unc, fmaxf(fmaf(pr.kapS[k], fabsf(bt.x), -fabsf(disc.x)), fmaf(pr.kapS[k], fabsf(bt.y), -fabsf(disc.y))));
+      unc = fmaxf(fmaxf(unc, fmaf(pr.kapS[k], fabsf(bt.x), -fabsf(disc.x))), fmaf(pr.kapS[k], fabsf(bt.y), -fabsf(disc.y)));   // one v_max3_f32
       if (LO) {                                                             // own sphere: handled after the loop
         if (OPAQUE) {
           v2f u = pk_fma(sg, sq, -bt);
@@ -221,7 +222,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     }
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
-      if (act & (0x10000u << k)) {
+      if (!NOPLANES && (act & (0x10000u << k))) {
         const v2f den = pk_fma(oj, lo2(D2n[k]), pk_fma(oi, hi2(D01[k]), lo2(D01[k])));   // N.ts
         const v2f tau = hi2(D2n[k]) * pk_rcp(den);                          // den == 0 -> inf/NaN -> miss
         v2f u = tau * d2;                                                   // same scale as the sphere roots
@@ -302,12 +303,15 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     }
     // the smallest positive root of the pair (a crossing at the shadow origin is not decided in fp32);
     // LO paths compare their roots with the 2e-6 bound themselves
-    if (OPAQUE) { if (!LO) mlow = umin3(mlow, m0, valid1 ? m1 : 0xFFFFFFFFu); }
+    if (OPAQUE) { if (!LO) mlow = umin3(mlow, m0, m1 | (valid1 ? 0u : 0xFFFFFFFFu)); }   // (scalar select + v_or + v_min3)
     else mlow = min(mlow, ml);
-    if (OPAQUE) total += (m0 < __float_as_uint(d2.x) ? 0.0f : 1.0f) + (m1 < __float_as_uint(d2.y) ? 0.0f : 1.0f);
+    // (opaque scenes count BLOCKED samples in an integer: compare + add-with-carry per sample; the second sample of an
+    // odd grid's last pair has m1 = 0 and counts as blocked, like the padding it is)
+    if (OPAQUE) n_blocked += (uint32_t)(m0 < __float_as_uint(d2.x)) + (uint32_t)(m1 < __float_as_uint(d2.y));
     else total += tr.x + (valid1 ? tr.y : 0.0f);
   }
   fl.unc = unc; fl.mlow = mlow; fl.dmin = dmin;
+  if (OPAQUE) total = (float)(2 * n_pairs - (int)n_blocked);
   return total;
 }
 
@@ -320,7 +324,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
                                                     float* __restrict__ fb, FixRec* __restrict__ fix) {
   constexpr int MAXN = MAXS + MAXP + MAXB;
   __shared__ Prim s_prims[MAXN];
-  __shared__ float2 s_cells[LS_MAX_CELLS];
+  // cell base offsets per light and SAMPLE PAIR q (cells 2q, 2q+1): (b0.x, b1.x, b0.y, b1.y), so that one 16-byte LDS
+  // read delivers the two packed operands of the pair (the second cell of an odd grid's last pair repeats cell 0)
+  __shared__ float4 s_cells[LS_MAX_CELLS / 2 + LS_MAX_LIGHTS];
   __shared__ float s_lightf[LS_MAX_LIGHTS][LIGHT_STRIDE];    // lights as fp32 (the shadow origin's epsilon lives in cc / num)
   __shared__ float4 s_sphf[MAXS];                             // sphere centres + radii as fp32
   // low parts: centre = s_sphf + s_sphl, light position = s_lightf[0..2] + s_lightl to ~1e-15; with the hit point split
@@ -364,12 +370,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     }
     for (int i = threadIdx.x; i < sc.nM * MAT_STRIDE; i += BLOCK) (&s_matd[0][0])[i] = sc.mats[i];
     // per-light table of cell base offsets: -radius/2 + cell*(i or j)   (ray_tracer.py:215, 224-225)
-    for (int e = threadIdx.x; e < sc.nL * n_cells; e += BLOCK) {
-      const int li = e / n_cells, c = e - li * n_cells;
-      const float radius = (float)sc.lights[LIGHT_STRIDE * li + 8];
-      const float cell = radius / (float)n_side, half = -0.5f * radius;
-      const int i = c / n_side, j = c - i * n_side;
-      s_cells[e] = n_sh > 1 ? make_float2(fmaf(cell, (float)i, half), fmaf(cell, (float)j, half)) : make_float2(0.0f, 0.0f);
+    {
+      const int n_pairs_ = (n_cells + 1) >> 1;
+      for (int e = threadIdx.x; e < sc.nL * n_pairs_; e += BLOCK) {
+        const int li = e / n_pairs_, q_ = e - li * n_pairs_;
+        const float radius = (float)sc.lights[LIGHT_STRIDE * li + 8];
+        const float cell = radius / (float)n_side, half = -0.5f * radius;
+        const int c0_ = 2 * q_, c1_ = 2 * q_ + 1 < n_cells ? 2 * q_ + 1 : 0;
+        const int i0 = c0_ / n_side, j0 = c0_ - i0 * n_side, i1 = c1_ / n_side, j1 = c1_ - i1 * n_side;
+        s_cells[e] = n_sh > 1 ? make_float4(fmaf(cell, (float)i0, half), fmaf(cell, (float)i1, half), fmaf(cell, (float)j0, half), fmaf(cell, (float)j1, half))
+                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     }
     for (int li = threadIdx.x; li < sc.nL; li += BLOCK) {
       const double* L = sc.lights + LIGHT_STRIDE * li;
@@ -755,7 +766,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         }
       }
       if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
-      const float2* cells = s_cells + li * n_cells;
+      const float4* cells = s_cells + li * ((n_cells + 1) >> 1);
       str_act = act & s_lstr[li];
       if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
       if (str_act != 0u) {
@@ -795,9 +806,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                      T0, T1, T2, tol.kap, fl, own);
         else if (MAXS > 2 && __popc(act & ((1u << MAXS) - 1u)) <= 2) {
-          // At most two spheres left for this (wave, light) — the usual case: their coefficients are moved to two
-          // dense slots (wave-uniform moves), and the sample loop runs in its two-sphere instantiation: per sample pair
-          // it then tests 2 instead of MAXS "is this sphere active" bits on the scalar unit (each a compare + branch).
+          // At most two spheres left for this (wave, light) — the usual case: their coefficients are moved to dense
+          // slots (wave-uniform moves) and the sample loop runs in an instantiation for exactly that many spheres,
+          // with or without the plane block: nothing about `act` is tested per sample pair any more.
           v2f gAB[2], gCc[2], gSg[1];
           float gtau[2], gkap[2];
           gAB[0] = gAB[1] = mk2(0.0f, 0.0f); gCc[0] = gCc[1] = mk2(0.0f, 1.0f); gSg[0] = mk2(-1.0f, -1.0f);
@@ -812,10 +823,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
               ++j;
             }
           }
-          LsPrims<2, MAXP, MAXB, OPAQUE> pr2{gAB, gCc, gSg, gtau, gkap, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
           const uint32_t act2 = (act & ~((1u << MAXS) - 1u)) | ((1u << j) - 1u);
-          total = ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up,
-                                                                T0, T1, T2, tol.kap, fl);
+          const bool nopl = ((act >> 16) & 0xFFu) == 0u;
+          if (j == 2) {
+            LsPrims<2, MAXP, MAXB, OPAQUE> pr2{gAB, gCc, gSg, gtau, gkap, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
+            total = nopl ? ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false, true, true>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl)
+                         : ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false, true, false>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl);
+          } else {
+            LsPrims<1, MAXP, MAXB, OPAQUE> pr1{reinterpret_cast<v2f(&)[1]>(gAB), reinterpret_cast<v2f(&)[1]>(gCc), gSg, reinterpret_cast<float(&)[1]>(gtau),
+                                               reinterpret_cast<float(&)[1]>(gkap), a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
+            if (j == 1)
+              total = nopl ? ls_light_sum<1, 1, MAXP, MAXB, OPAQUE, false, true, true>(pr1, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl)
+                           : ls_light_sum<1, 1, MAXP, MAXB, OPAQUE, false, true, false>(pr1, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl);
+            else      // planes / boxes only
+              total = ls_light_sum<1, 1, MAXP, MAXB, OPAQUE, false>(pr1, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl);
+          }
         } else
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                       T0, T1, T2, tol.kap, fl);
