@@ -329,6 +329,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   __shared__ float4 s_cells[LS_MAX_CELLS / 2 + LS_MAX_LIGHTS];
   __shared__ float s_lightf[LS_MAX_LIGHTS][LIGHT_STRIDE];    // lights as fp32 (the shadow origin's epsilon lives in cc / num)
   __shared__ float4 s_sphf[MAXS];                             // sphere centres + radii as fp32
+  __shared__ float4 s_plnf[MAXP > 0 ? MAXP : 1];               // plane normals as fp32 (the light loop reads them per (hit, light))
   // low parts: centre = s_sphf + s_sphl, light position = s_lightf[0..2] + s_lightl to ~1e-15; with the hit point split
   // the same way (pf + pl), oc and tl carry only a few ulp of THEIR size instead of ulps of the coordinates' size
   __shared__ float4 s_sphl[MAXS];
@@ -362,6 +363,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         s_sphf[i] = h;
         s_sphl[i] = make_float4((float)(a[0] - (double)h.x), (float)(a[1] - (double)h.y), (float)(a[2] - (double)h.z), 0.0f);
       }
+    }
+    for (int i = threadIdx.x; i < MAXP; i += BLOCK) {
+      s_plnf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (i < sc.nP) { const double* a = sc.prims[sc.nS + i].a; s_plnf[i] = make_float4((float)a[0], (float)a[1], (float)a[2], 0.0f); }
     }
     for (int i = threadIdx.x; i < sc.nL * 3; i += BLOCK) {
       const int li = i / 3, c = i - li * 3;
@@ -709,8 +714,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         for (int k = 0; k < MAXP; ++k) {
           a_D01[k] = mk2(0.0f, 0.0f); a_D2n[k].x = 0.0f;
           if (k < nP) {
-            const Prim& s_ = P[nS + k];
-            const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+            const float4 nf4 = s_plnf[k];
+            const f3 N = mkf(nf4.x, nf4.y, nf4.z);
             const float D0_ = dotf(N, tl), num_ = a_D2n[k].y;
             a_D01[k].x = D0_;
             // |N.right| + |N.up| <= sqrt2 |N - (N.ld) ld|, N unit (to 0.1 %)
@@ -760,8 +765,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
         if (k < nP && ((act >> (16 + k)) & 1u)) {
-          const Prim& s_ = P[nS + k];
-          const f3 N = mkf((float)s_.a[0], (float)s_.a[1], (float)s_.a[2]);
+          const float4 nf4 = s_plnf[k];
+          const f3 N = mkf(nf4.x, nf4.y, nf4.z);
           a_D01[k].y = dotf(N, right); a_D2n[k].x = dotf(N, up);
         }
       }
