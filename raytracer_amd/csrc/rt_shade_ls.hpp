@@ -977,8 +977,12 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
     if (ds.nS <= 2) RT_LS(2, 2, 0);
     if (ds.nS <= 4) RT_LS(4, 2, 0);
     if (ds.nS <= 6) RT_LS(6, 2, 0);
-    // 7-8 spheres: the 8-sphere instantiation needs > 256 VGPRs (1 wave/SIMD) and measured slower than
-    // k_shade_fast with its candidate sets (pool + 2 spheres at 4K: 4.5 ms vs 3.9 ms)
+    // 7-16 spheres: the per-hit coefficient arrays no longer fit 256 VGPRs (22 / 60 / 108 spilled at 8 / 12 / 16), but
+    // the sample loop runs in its dense 1- / 2-sphere instantiations almost always, so the spills sit outside it:
+    // pool + 2 spheres at 4K 2.5 ms against 9.7 ms through k_shade_fast
+    if (ds.nS <= 8) RT_LS(8, 2, 0);
+    if (ds.nS <= 12) RT_LS(12, 2, 0);
+    if (ds.nS <= 16) RT_LS(16, 2, 0);
   } else if (ds.nB <= 4) {
     if (ds.nS <= 2) RT_LS(2, 2, 4);
     if (ds.nS <= 4) RT_LS(4, 2, 4);
