@@ -24,7 +24,7 @@ cam.setup(W / H)
 with GpuScene(pack_scene(mats, surfs, lights, st.background_color)) as gs:
     best = None
     for _ in range(frames):
-        gs.render(cam, W, H, 5, 3, precision="fp32", jitter=1234, flags=_lib.RT_FLAG_TIMING)
+        gs.render(cam, W, H, int(os.environ.get("N_SH", "5")), 3, precision="fp32", jitter=1234, flags=_lib.RT_FLAG_TIMING)
         s = gs.last_stats
         if best is None or s["total_ms"] < best["total_ms"]:
             best = dict(s)
