@@ -986,6 +986,9 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
   } else if (ds.nB <= 4) {
     if (ds.nS <= 2) RT_LS(2, 2, 4);
     if (ds.nS <= 4) RT_LS(4, 2, 4);
+    // (more spheres with boxes: the box path leaves too many (hit, light) pairs to the exact re-test — slab roots near an
+    // edge or a direction nearly parallel to a slab are never decided in fp32 —, measured 16.5 ms against 6.6 ms through
+    // k_shade_fast for pool + 2 boxes at 4K)
   }
 #undef RT_LS
   return false;

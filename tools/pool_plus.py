@@ -17,6 +17,9 @@ c = np.array([[float(v) for v in s_[1:4]] for s_ in sph]); r = float(sph[0][4])
 for i in range(k):
     pos = c.mean(0) + np.array([rng.uniform(-1.5, 1.5), 0.0, rng.uniform(-1.5, 1.5)])
     text += f"sph {pos[0]:.4f} {pos[1]:.4f} {pos[2]:.4f} {r} {sph[i % len(sph)][5]}\n"
+for i in range(int(os.environ.get("N_BOX", "0"))):      # extra boxes on the table ("box cx cy cz edge material")
+    pos = c.mean(0) + np.array([rng.uniform(-2.5, 2.5), 0.0, rng.uniform(-2.5, 2.5)])
+    text += f"box {pos[0]:.4f} {pos[1] - r + 0.4:.4f} {pos[2]:.4f} 0.8 {sph[i % len(sph)][5]}\n"
 cam, st, objs = parse_scene_text(text)
 mats, surfs, lights = separate_objects(objs)
 W, H = 3840, 2160
