@@ -719,14 +719,17 @@ extern "C" int rt_sync(rt_scene* s) try {
   return rc;
 } RT_CATCH_ALL
 
-// Bounce-ray queues: a blocking frame starts with 0.55 slots per pixel and queue (the pool scene's largest bounce
-// level holds 0.42 rays per pixel, its fullest queue segment 17 % more than the mean; at 7680x4320 the workspace is
-// then 3.5 GB instead of 11 GB; RT_QUEUE_SLOTS_PER_PIXEL overrides) and relies on
+// Bounce-ray queues: a blocking frame starts with 2 slots per pixel and queue as long as that stays below ~3 GB, and
+// with as little as 0.55 per pixel for larger row sets (the pool scene's largest bounce level holds 0.42 rays per
+// pixel, its fullest queue segment 17 % more than the mean; at 7680x4320 the workspace is then 3.5 GB instead of
+// 11 GB; RT_QUEUE_SLOTS_PER_PIXEL overrides), and relies on
 // the overflow retry of rt_render, which re-renders with the size the overflowing level asked for; the sizes only
 // ever grow, so later frames of the scene start where the last retry ended.  Frames that cannot be retried
 // (RT_FLAG_ASYNC) get the old worst-case-ish 2 slots per pixel unless the workspace is larger already.
 static int ensure_workspace(rt_scene* s, size_t pixels, size_t out_bytes, bool need_out, bool can_retry, bool need_fb = true) {
-  double per_pixel = can_retry ? 0.55 : 2.0;
+  // 2 slots per pixel while the two queues + hit list stay below ~3 GB (up to ~9 M pixels: a 4K frame never needs the
+  // retry), shrinking to 0.55 per pixel for larger row sets (8K: 3.5 GB)
+  double per_pixel = can_retry ? std::min(2.0, std::max(0.55, 3.0e9 / (168.0 * (double)std::max<size_t>(pixels, 1)))) : 2.0;
   if (const char* e = getenv("RT_QUEUE_SLOTS_PER_PIXEL")) per_pixel = std::min(64.0, std::max(0.01, atof(e)));
   const size_t base_q = (size_t)(per_pixel * (double)pixels) + 65536;      // (the constant: small frames fill their 64 segments unevenly)
   const size_t want_q = std::max<size_t>(base_q, s->min_queue);

@@ -8,9 +8,7 @@ OUT=${1:-/root/repo/gpurun_out/kstats}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in pool4k original1080 pool8k synth4k; do
-  # steady-state frames only: the synthetic scene's first frame would overflow the default 0.55 queue slots per pixel
-  # (its largest bounce level holds 1.13 rays per pixel) and be rendered twice, which would sit in the averages
-  if [ "$w" = synth4k ]; then export RT_QUEUE_SLOTS_PER_PIXEL=1.5; else unset RT_QUEUE_SLOTS_PER_PIXEL; fi
+  unset RT_QUEUE_SLOTS_PER_PIXEL
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -- \
     python3 /root/repo/tools/quick_bench.py "$w" --frames 3 > "$OUT/$w.log" 2>&1 || { echo "$w failed"; tail -5 "$OUT/$w.log"; exit 1; }
   cp "$(ls "$OUT/$w"/*/*kernel_stats.csv | head -1)" "$OUT/${w}_kernel_stats.csv" && echo "$w ok"
