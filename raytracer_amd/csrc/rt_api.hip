@@ -672,6 +672,10 @@ static int drain(rt_scene* s) {
       fprintf(stderr, "[rt debug] k_shade_ls re-test causes: %llu pairs; light's sample square touches a candidate %llu; of the rest (a pair can have several): "
               "grazing discriminant %llu, root at the shadow origin %llu, parallel to a plane %llu, light within 3 radii %llu, far hit %llu\n",
               w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_forced_cause), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_forced_cause), z, sizeof z);
+      fprintf(stderr, "[rt debug]   forced by special cases: own-sphere root near 2e-6 %llu, own-plane root %llu, direction parallel to a slab %llu, "
+              "box edge / root at the sample end %llu, own-box root near 2e-6 %llu\n", w[0], w[1], w[2], w[3], w[4]);
     }
 #endif
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS"))

@@ -62,6 +62,13 @@ constexpr int LS_MAX_CELLS = 1024;   // lights x n^2 entries of the per-block sa
 constexpr int LS_MAX_LIGHTS = 16;    // lights / materials staged in LDS (uniform global loads inside the
 constexpr int LS_MAX_MATS = 32;      // light loop were emitted as vector loads + full-latency waits)
 constexpr float LS_U = 6.0e-8f;      // 2^-24, the unit roundoff of fp32
+// "not decided in fp32" forced by a special case: any value above every real bound; the audit build tags the cases
+// (own-sphere root near 2e-6 / own-plane root / direction parallel to a slab / box edge or sample-end root / own-box root)
+#ifdef RT_DEBUG_KERNEL
+#define RT_UNC_FORCED(tag) (tag)
+#else
+#define RT_UNC_FORCED(tag) 3.0e38f
+#endif
 
 // Per-hit (cc, sgn, num, box slabs) and per-light (A, B, C, D*) primitive terms live in plain local
 // arrays of the kernel (fully unrolled, compile-time indices -> VGPRs); this is a view of references
@@ -210,7 +217,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
         // a root within 1e-3 (relative, squared) of the 2e-6 bound is not decided in fp32
         const bool nr = (fabsf(s1.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s1.y - lo2_.y) <= 1e-3f * lo2_.y) |
                         (fabsf(s2.x - lo2_.x) <= 1e-3f * lo2_.x) | (fabsf(s2.y - lo2_.y) <= 1e-3f * lo2_.y);
-        unc = nr ? 3.0e38f : unc;
+        unc = nr ? RT_UNC_FORCED(3.01e38f) : unc;
         unc = fmaxf(unc, fmaxf(fmaf(okap, fabsf(bt.x), -fabsf(disc.x)), fmaf(okap, fabsf(bt.y), -fabsf(disc.y))));
       }
       if (OPAQUE) {
@@ -230,7 +237,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
         if (LO) {   // exact lower bound of the reference: tau*|ts| > 2e-6 (own plane, light behind it)
           const v2f t2 = tau * u;
           const bool nr = (fabsf(t2.x - T_LO * T_LO) <= 1e-3f * T_LO * T_LO) | (fabsf(t2.y - T_LO * T_LO) <= 1e-3f * T_LO * T_LO);
-          unc = nr ? 3.0e38f : unc;
+          unc = nr ? RT_UNC_FORCED(3.02e38f) : unc;
           u.x = t2.x > T_LO * T_LO ? u.x : -1.0f; u.y = t2.y > T_LO * T_LO ? u.y : -1.0f;
         }
         if (OPAQUE) { m0 = min(m0, __float_as_uint(u.x)); m1 = min(m1, __float_as_uint(u.y)); }
@@ -252,7 +259,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
           const float lim = 1e-6f * T0;     // (1e-3 |tl|)^2
           const bool par = (tsx.x * tsx.x < lim) | (tsx.y * tsx.y < lim) | (tsy.x * tsy.x < lim) | (tsy.y * tsy.y < lim) |
                            (tsz.x * tsz.x < lim) | (tsz.y * tsz.y < lim);
-          unc = par ? 3.0e38f : unc;
+          unc = par ? RT_UNC_FORCED(3.03e38f) : unc;
         }
 #pragma unroll
         for (int k = 0; k < MAXB; ++k) {
@@ -268,18 +275,25 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
             {
               // the ray passes an edge of the box within the slabs' rounding (relative 4e-3 with the 1e-3 limit
               // above), or a slab root lies at the sample itself (tau = 1): not decided in fp32
-              const bool edge = (fabsf(tf.x - tn.x) <= 4e-3f * (fabsf(tn.x) + fabsf(tf.x))) | (fabsf(tf.y - tn.y) <= 4e-3f * (fabsf(tn.y) + fabsf(tf.y))) |
-                                (fabsf(tn.x - 1.0f) <= 4e-3f) | (fabsf(tn.y - 1.0f) <= 4e-3f) | (fabsf(tf.x - 1.0f) <= 4e-3f) | (fabsf(tf.y - 1.0f) <= 4e-3f);
-              unc = edge ? 3.0e38f : unc;
+              // (only where it can matter: a degenerate interval [tn, tf] that overlaps the segment's (0, 1), a sample-end
+              // root of a box that is not clearly missed — a box whose slab roots all lie beyond the light needs no decision)
+              const float g0 = 4e-3f * (fabsf(tn.x) + fabsf(tf.x)), g1 = 4e-3f * (fabsf(tn.y) + fabsf(tf.y));
+              const bool graze0 = (fabsf(tf.x - tn.x) <= g0) & (fminf(tn.x, tf.x) < 1.004f) & (fmaxf(tn.x, tf.x) > -4e-3f);
+              const bool graze1 = (fabsf(tf.y - tn.y) <= g1) & (fminf(tn.y, tf.y) < 1.004f) & (fmaxf(tn.y, tf.y) > -4e-3f);
+              const bool end0 = (tf.x - tn.x >= -g0) & ((fabsf(tn.x - 1.0f) <= 4e-3f) | (fabsf(tf.x - 1.0f) <= 4e-3f));
+              const bool end1 = (tf.y - tn.y >= -g1) & ((fabsf(tn.y - 1.0f) <= 4e-3f) | (fabsf(tf.y - 1.0f) <= 4e-3f));
+              const bool edge = graze0 | graze1 | end0 | end1;
+              unc = edge ? RT_UNC_FORCED(3.04e38f) : unc;
             }
             if (LO) {                                                      // see the sphere slow path
               const float lo0 = T_LO * T_LO * raw_rcp(d2.x), lo1 = T_LO * T_LO * raw_rcp(d2.y);   // tau^2 > 4e-12 / |ts|^2
               const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
               const bool a0 = ok0 & in_open(tn.x, 1.0f) & (tn.x * tn.x > lo0), a1 = ok1 & in_open(tn.y, 1.0f) & (tn.y * tn.y > lo1);
               const bool b0 = ok0 & in_open(tf.x, 1.0f) & (tf.x * tf.x > lo0), b1 = ok1 & in_open(tf.y, 1.0f) & (tf.y * tf.y > lo1);
-              const bool nr = (fabsf(tn.x * tn.x - lo0) <= 2e-2f * lo0) | (fabsf(tn.y * tn.y - lo1) <= 2e-2f * lo1) |
-                              (fabsf(tf.x * tf.x - lo0) <= 2e-2f * lo0) | (fabsf(tf.y * tf.y - lo1) <= 2e-2f * lo1);
-              unc = nr ? 3.0e38f : unc;
+              // a root within 1 % of the 2e-6 bound — a POSITIVE root of a box that is hit (a root behind the origin is no crossing)
+              const bool nr = (ok0 & (((tn.x > 0.0f) & (fabsf(tn.x * tn.x - lo0) <= 2e-2f * lo0)) | ((tf.x > 0.0f) & (fabsf(tf.x * tf.x - lo0) <= 2e-2f * lo0)))) |
+                              (ok1 & (((tn.y > 0.0f) & (fabsf(tn.y * tn.y - lo1) <= 2e-2f * lo1)) | ((tf.y > 0.0f) & (fabsf(tf.y * tf.y - lo1) <= 2e-2f * lo1))));
+              unc = nr ? RT_UNC_FORCED(3.05e38f) : unc;
               if (OPAQUE) { m0 = (a0 | b0) ? 0u : m0; m1 = (a1 | b1) ? 0u : m1; }
               else {
                 const float ta = pr.tauB[k];
@@ -852,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
         undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far;
         if (RT_DBG(fp) & (1u << 23))    // cause bits: 1 grazing discriminant, 2 root at the origin, 4 parallel plane, 8 light close, 16 far
-          dbg_cause = (!(fl.unc < -tol.kap0) ? 1u : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
+          dbg_cause = ((!(fl.unc < -tol.kap0) && fl.unc < 3.0e38f) ? 1u : 0u) | (fl.unc >= 3.005e38f ? (32u << (int)((fl.unc - 3.005e38f) * 1e-36f)) : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
                       (((T0 < 9.0f * RL * RL) | !(T0 > 1e-12f)) ? 8u : 0u) | (far ? 16u : 0u);
       }
       }   // phase B
@@ -874,6 +888,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         atomicAdd(&g_fix_cause[0], 1ull);
         if (str_act != 0u) atomicAdd(&g_fix_cause[1], 1ull);
         for (int b_ = 0; b_ < 5; ++b_) if (dbg_cause & (1u << b_)) atomicAdd(&g_fix_cause[2 + b_], 1ull);
+        for (int b_ = 0; b_ < 5; ++b_) if (dbg_cause & (32u << b_)) atomicAdd(&g_forced_cause[b_], 1ull);
 #endif
       }
       if (undecided) total = 0.0f;
