@@ -17,7 +17,9 @@
 //    all crossings.  The fast kernel forms that product directly from both roots of every
 //    primitive: crossing parameter t' measured from p is in range iff 2e-6 < t' < dist (the
 //    reference starts at p + dir*1e-6, accepts t > 1e-6 and stops at dist - 1e-6).
-//    Differences to the walk (early stop below 1e-6, 20-step cap, crossings closer than 1e-6 to
+//    The walk stops after 20 crossings (ray_tracer.py:257): scenes with transparency count, per (hit, light, chunk),
+//    the primitives a sample can cross (an upper bound of every sample's crossings) and leave pairs that may exceed 20
+//    to the exact re-test.  The other differences to the walk (early stop below 1e-6, crossings closer than 1e-6 to
 //    each other) are below the fp32 tolerance.
 #pragma once
 #include "rt_kernels.hpp"
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           // whole (hit, light) pair undecided (-> re-test queue).  ONE fp64 site per chunk instead of one per test site:
           // inlined behind every sample block the exact code cost 83 spilled VGPRs and 5 ms of a 22 ms frame.
           int dk0 = -1, dk1 = -1; uint32_t dm0 = 0u, dm1 = 0u;
+          int ncross = 0;   // scenes with transparency: roots in range, any sample (the walk multiplies at most 20 crossings)
           auto retest = [&](int k_, uint32_t fmask) __attribute__((always_inline)) {
             if (fmask != 0u) {
               if (dk0 < 0) { dk0 = k_; dm0 = fmask; }
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             // (t1 t2 = cc): the hit's own sphere, or one touching it at the hit point
             const bool nearsurf = fabsf(cc) <= 1.2e-5f * (ocn + r_);
             uint32_t fmask = 0u;
+            bool any1 = false, any2 = false;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float b = fmaf(oc.z, dz[s], fmaf(oc.y, dy[s], oc.x * dx[s]));   // oc.d  (a = d.d = 1)
@@ -303,7 +307,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               f &= (c * CH + s) < n_cells;
               if (!f) apply(tr[s], in1, in2, tau);
               fmask |= f ? (1u << s) : 0u;
+              if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
+            if (!OPAQUE) ncross += (int)any1 + (int)any2;
             retest(k_, fmask);
           };
           auto do_box = [&](const Prim& s_, int k_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float fmin_ = fminf(fminf(fminf(fabsf(lo.x), fabsf(hi.x)), fminf(fabsf(lo.y), fabsf(hi.y))), fminf(fabsf(lo.z), fabsf(hi.z)));
             const bool nearsurf = fmin_ <= 1.2e-5f;
             uint32_t fmask = 0u;
+            bool any1 = false, any2 = false;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float jx = KEEP_INV ? ix[KEEP_INV ? s : 0] : raw_rcp(dx[s]), jy = KEEP_INV ? iy[KEEP_INV ? s : 0] : raw_rcp(dy[s]),
@@ -346,7 +353,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               f &= (c * CH + s) < n_cells;
               if (!f) apply(tr[s], in1, in2, tau);
               fmask |= f ? (1u << s) : 0u;
+              if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
+            if (!OPAQUE) ncross += (int)any1 + (int)any2;
             retest(k_, fmask);
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
@@ -359,6 +368,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             if (fabsf(fmaf(N.z, tl.z, fmaf(N.y, tl.y, N.x * tl.x)) - num) <= reach + 1e-5f * fabsf(num)) unc = 1.0f;
             const bool nearsurf = fabsf(num) <= 1.2e-5f;                 // p on the plane: the hit's own plane
             uint32_t fmask = 0u;
+            bool any1 = false;
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
               const float den = fmaf(N.z, dz[s], fmaf(N.y, dy[s], N.x * dx[s]));
@@ -369,7 +379,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               f &= (c * CH + s) < n_cells;
               if (!f) apply(tr[s], in1, false, tau);
               fmask |= f ? (1u << s) : 0u;
+              if (!OPAQUE) any1 |= in1;
             }
+            if (!OPAQUE) ncross += (int)any1;
             retest(k, fmask);
           }
           if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             dm0 &= dm0 - 1u;
             if (dm0 == 0u) { dk0 = dk1; dm0 = dm1; dk1 = -1; dm1 = 0u; }
           }
+          if (!OPAQUE && ncross > WALK_CAP && !fp.sequential) unc = 1.0f;   // a sample may cross more surfaces than the walk visits
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
         }

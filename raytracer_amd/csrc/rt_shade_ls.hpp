@@ -980,6 +980,9 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
                             hipStream_t st) {
   const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
   if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
+  // scenes with transparency: the reference's shadow walk multiplies at most 20 crossings (ray_tracer.py:257); this kernel
+  // forms the product over all of them, so it only serves scenes where no segment can cross more (k_shade_fast counts)
+  if (!opaque && !fp.sequential && 2 * ds.nS + ds.nP + 2 * ds.nB > WALK_CAP) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \

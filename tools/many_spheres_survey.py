@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""fp32-vs-oracle sweep over random 7-16 sphere scenes (tests/test_gpu_many_spheres.py's generator): tools/many_spheres_survey.py [n_seeds]"""
+"""fp32-vs-oracle sweep over random 7-16 sphere scenes (tests/test_gpu_many_spheres.py's generator): tools/many_spheres_survey.py [n_seeds [first_seed]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -10,8 +10,9 @@ from raytracer_amd.image import quantize_u8
 from oracle import oracle
 oracle.set_threads(16)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; worst = 0
-for seed in range(N):
+for seed in range(FIRST, FIRST + N):
     n_sph = 7 + seed % 10
     cam, st, objs = parse_scene_text(many_spheres_text(n_sph, 5000 + seed, seed % 2 == 1))
     mats, surfs, lights = separate_objects(objs)
