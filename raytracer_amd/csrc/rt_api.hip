@@ -319,6 +319,7 @@ struct rt_scene {
   float* d_hpair = nullptr; uint8_t* d_haxis = nullptr; uint32_t* d_hleaf = nullptr;    // heap-layout tree for nearest-hit walks
   bool pool_trace = false;                                   // bounce levels through k_trace_pool (needs the heap trees)
   bool all_opaque = true;
+  int n_coincident = 0;    // primitives marked by mark_coincident (scenes with transparency)
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_hits = 0, cap_out = 0;
@@ -363,6 +364,63 @@ static void free_workspace(rt_scene* s) {
   s->d_fb = s->d_out = nullptr; s->d_hits = nullptr;
   s->d_qbuf[0] = s->d_qbuf[1] = nullptr; s->d_qpix[0] = s->d_qpix[1] = nullptr;
   s->cap_pixels = s->cap_queue = s->cap_hits = s->cap_out = s->cap_fb = 0;
+}
+
+// Scenes with transparency, fp32 mode.  The reference's shadow walk steps 1e-6 past every crossing and accepts the next
+// one only beyond another 1e-6 (ray_tracer.py:287-288 with the surfaces' t > 1e-6 thresholds), so two crossings within
+// 2e-6 of each other along a segment count ONCE; the fp32 kernels' product over all crossings counts both.  Between
+// different primitives that is systematic only where surfaces coincide: box faces on box faces or on a plane, duplicated
+// spheres / planes (tangent contacts are a set of measure zero).  One primitive of every such pair is marked here
+// (Prim::pad bit 0); a (hit, light) pair whose samples cross a marked primitive is left to the exact walk.
+static int mark_coincident(std::vector<Prim>& prims) {
+  const double TOL = 2.5e-6;
+  int marked = 0;
+  auto mark = [&](Prim& p) { if (!(p.pad & 1)) { p.pad |= 1; ++marked; } };
+  struct Face { double c; int prim; };
+  for (int ax = 0; ax < 3; ++ax) {
+    const int u = (ax + 1) % 3, v = (ax + 2) % 3;
+    std::vector<Face> f;
+    for (size_t i = 0; i < prims.size(); ++i)
+      if (prims[i].type == RT_BOX) { f.push_back({prims[i].a[ax], (int)i}); f.push_back({prims[i].a[3 + ax], (int)i}); }
+    std::sort(f.begin(), f.end(), [](const Face& x, const Face& y) { return x.c < y.c; });
+    for (size_t i = 0; i < f.size(); ++i) {
+      Prim& A = prims[f[i].prim];
+      int budget = 4096;                      // many boxes on one level: give up on the pair tests and mark this one
+      for (size_t j = i + 1; j < f.size() && f[j].c - f[i].c <= TOL; ++j) {
+        if (f[j].prim == f[i].prim) continue;
+        if (--budget < 0) { mark(A); break; }
+        const Prim& B = prims[f[j].prim];
+        if (A.a[u] <= B.a[3 + u] + TOL && B.a[u] <= A.a[3 + u] + TOL && A.a[v] <= B.a[3 + v] + TOL && B.a[v] <= A.a[3 + v] + TOL) { mark(A); break; }
+      }
+    }
+    for (const Prim& pl : prims) {            // a box face lying in a plane
+      if (pl.type != RT_PLANE || std::fabs(pl.a[ax]) < 1.0 - 1e-9) continue;
+      const double c = pl.a[3] / pl.a[ax];
+      for (Prim& b : prims)
+        if (b.type == RT_BOX && (std::fabs(b.a[ax] - c) <= TOL || std::fabs(b.a[3 + ax] - c) <= TOL)) mark(b);
+    }
+  }
+  std::vector<Face> sp;
+  for (size_t i = 0; i < prims.size(); ++i) if (prims[i].type == RT_SPHERE) sp.push_back({prims[i].a[0], (int)i});
+  std::sort(sp.begin(), sp.end(), [](const Face& x, const Face& y) { return x.c < y.c; });
+  for (size_t i = 0; i < sp.size(); ++i) {
+    Prim& A = prims[sp[i].prim];
+    int budget = 4096;
+    for (size_t j = i + 1; j < sp.size() && sp[j].c - sp[i].c <= TOL; ++j) {
+      if (--budget < 0) { mark(A); break; }
+      const Prim& B = prims[sp[j].prim];
+      if (std::fabs(A.a[1] - B.a[1]) <= TOL && std::fabs(A.a[2] - B.a[2]) <= TOL && std::fabs(A.a[3] - B.a[3]) <= TOL) { mark(A); break; }
+    }
+  }
+  std::vector<int> pl;
+  for (size_t i = 0; i < prims.size(); ++i) if (prims[i].type == RT_PLANE) pl.push_back((int)i);
+  for (size_t i = 0; i < pl.size() && i < 4096; ++i)
+    for (size_t j = i + 1; j < pl.size() && j < 4096; ++j) {
+      Prim& A = prims[pl[i]]; const Prim& B = prims[pl[j]];
+      const double d = A.a[0] * B.a[0] + A.a[1] * B.a[1] + A.a[2] * B.a[2];
+      if (std::fabs(d) >= 1.0 - 1e-12 && std::fabs(A.a[3] - (d > 0 ? B.a[3] : -B.a[3])) <= TOL) { mark(A); break; }
+    }
+  return marked;
 }
 
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) try {
@@ -455,9 +513,14 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (int i = 0; i < desc->n_lights; ++i)
     for (int k = 0; k < 9; ++k) lights[(size_t)i * LIGHT_STRIDE + k] = desc->lights[(size_t)i * 9 + k];
 
+  bool any_transparent = false;
+  for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) any_transparent = true;
+  const int n_coincident = any_transparent ? mark_coincident(prims) : 0;
+
   rt_scene* s = new (std::nothrow) rt_scene();
   if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
   s->device = device;
+  s->n_coincident = n_coincident;
   auto bail = [&](int code) { rt_scene_destroy(s); return code; };
 #define HIPCHK_S(call)                                                                         \
   do {                                                                                         \
@@ -860,7 +923,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
+        if (s->shade_variant == 0 && s->n_coincident == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
         if (!done)
           launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
       }

@@ -19,8 +19,9 @@
 //    reference starts at p + dir*1e-6, accepts t > 1e-6 and stops at dist - 1e-6).
 //    The walk stops after 20 crossings (ray_tracer.py:257): scenes with transparency count, per (hit, light, chunk),
 //    the primitives a sample can cross (an upper bound of every sample's crossings) and leave pairs that may exceed 20
-//    to the exact re-test.  The other differences to the walk (early stop below 1e-6, crossings closer than 1e-6 to
-//    each other) are below the fp32 tolerance.
+//    to the exact re-test.  Crossings within 2e-6 of each other count once in the walk: systematic only where surfaces of two
+//    primitives coincide, which scene creation marks (Prim::pad) — pairs crossing a marked primitive go to the exact
+//    re-test as well.  The early stop below 1e-6 is below the fp32 tolerance.
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -309,7 +310,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               fmask |= f ? (1u << s) : 0u;
               if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
-            if (!OPAQUE) ncross += (int)any1 + (int)any2;
+            if (!OPAQUE) {
+              ncross += (int)any1 + (int)any2;
+              if ((s_.pad & 1) && (any1 | any2)) unc = 1.0f;   // coincident surfaces: the walk counts two crossings once
+            }
             retest(k_, fmask);
           };
           auto do_box = [&](const Prim& s_, int k_) __attribute__((always_inline)) {      // cube.py:76-107 (slab roots)
@@ -355,7 +359,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               fmask |= f ? (1u << s) : 0u;
               if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
-            if (!OPAQUE) ncross += (int)any1 + (int)any2;
+            if (!OPAQUE) {
+              ncross += (int)any1 + (int)any2;
+              if ((s_.pad & 1) && (any1 | any2)) unc = 1.0f;   // coincident surfaces: the walk counts two crossings once
+            }
             retest(k_, fmask);
           };
           for (int k = sc.nS, e = sc.nS + sc.nP; k < e; ++k) {   // planes: infinite_plane.py:30-42
@@ -381,7 +388,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               fmask |= f ? (1u << s) : 0u;
               if (!OPAQUE) any1 |= in1;
             }
-            if (!OPAQUE) ncross += (int)any1;
+            if (!OPAQUE) {
+              ncross += (int)any1;
+              if ((s_.pad & 1) && any1) unc = 1.0f;
+            }
             retest(k, fmask);
           }
           if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {

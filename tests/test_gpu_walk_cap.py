@@ -77,3 +77,46 @@ def test_stress_scene_349(oracle):
     d8 = np.abs(_q(img32) - _q(ref))
     print(f"fp32 max 8-bit diff {d8.max()}, {(d8 > 1).sum()} channels > 1, {s32['retested']} of {3 * s32['hits']} pairs re-tested")
     assert d8.max() <= 1
+
+
+# --- crossings closer than 2e-6 to each other count once in the walk: coincident surfaces ---------------------------
+
+def glass_blocks_text(tau, floor_tau, below):
+    """Transparent cubes stacked and side by side (shared faces, exactly representable coordinates), standing on the
+    floor plane (bottom faces in the plane), a duplicated sphere and a duplicated plane."""
+    cam = "cam 0.3 -3.5 7 0.5 1.5 0 0 1 0 1.4 2" if below else "cam 2.5 3.5 8 0.5 1.2 0 0 1 0 1.4 2"
+    lines = [cam, "set 0.2 0.25 0.3 3 3",
+             f"mtl 0.8 0.8 0.8 0.3 0.3 0.3 0.1 0.1 0.1 10 {floor_tau}",
+             f"mtl 0.3 0.6 0.9 0.6 0.6 0.6 0.05 0.05 0.05 40 {tau}",
+             f"mtl 0.9 0.5 0.2 0.6 0.6 0.6 0.0 0.0 0.0 20 {tau}",
+             "mtl 0.9 0.9 0.2 0.5 0.5 0.5 0.0 0.0 0.0 20 0",
+             "pln 0 1 0 0 1", "pln 0 0 1 -6 1", "pln 0 0 1 -6 1"]
+    for x in (0.0, 1.0):
+        for y in (0.5, 1.5, 2.5):
+            lines.append(f"box {x} {y} 0 1 {2 + int(x + y) % 2}")
+    lines.append("box 2.25 0.25 0.5 0.5 2")             # smaller block against the side of the wall, on the floor
+    lines.append("sph -2 1 0.5 0.8 2"); lines.append("sph -2 1 0.5 0.8 3")     # the same sphere twice
+    lines.append("sph 0.5 3.6 -1.5 0.4 4")
+    lines.append("lgt -6 2.2 1.5 1 1 1 1 0.9 0.6")      # low: segments run through the vertical shared faces
+    lines.append("lgt 0.8 9 0.7 0.8 0.8 0.7 1 0.8 1.0")  # high: through the horizontal ones
+    lines.append("lgt 5 -4 3 0.6 0.6 0.6 1 0.7 0.0")     # below the floor
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("tau,floor_tau,below", [(0.7, 0.0, False), (0.5, 0.6, False), (0.7, 0.5, True), (1.0, 0.3, True)])
+def test_coincident_surfaces(oracle, tau, floor_tau, below):
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.render import render_hip
+    cam, st, objs = parse_scene_text(glass_blocks_text(tau, floor_tau, below))
+    mats, surfs, lights = separate_objects(objs)
+    W, H = 120, 90
+    ref, ostats = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 11), return_stats=True)
+    s64, s32 = {}, {}
+    img64 = render_hip(cam, st, mats, surfs, lights, W, H, precision="fp64", jitter=("pixel", 11), stats=s64, verbose=False)
+    img32 = render_hip(cam, st, mats, surfs, lights, W, H, precision="fp32", jitter=("pixel", 11), stats=s32, verbose=False)
+    assert rel_err(img64, ref).max() < 1e-9
+    for k in ("rays", "hits", "shadow_rays"):
+        assert s64[k] == ostats[k] and s32[k] == ostats[k], k
+    d8 = np.abs(_q(img32) - _q(ref))
+    print(f"tau {tau} floor {floor_tau} below {below}: fp32 max 8-bit diff {d8.max()}, {(d8 > 1).sum()} channels > 1, {s32['retested']} of {3 * s32['hits']} pairs re-tested")
+    assert d8.max() <= 1
