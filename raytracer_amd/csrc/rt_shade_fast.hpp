@@ -144,6 +144,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         const float T0x = dotf(tl, tl);
         // the light within 3 sample-square radii of the hit
         if ((T0x < 9.0f * RLx * RLx) | !(T0x > 1e-12f)) unc = 1.0f;
+        if (RT_DBG(fp) & 16777216u) unc = 1.0f;
         // reach of the sample square + the error of a shadow segment's far end (grows with the segment's length)
         const float reach = RLx + 1e-5f * (1.0f + fabsf((float)lg[0]) + fabsf((float)lg[1]) + fabsf((float)lg[2])) + 2.0f * U8 * raw_sqrt(T0x);
         // LDS-staged scenes (<= 128 records): conservative candidate set of this (wave, light) and the
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           cand = fc.act; lane_lit = !fc.lane_can; lane_dark = fc.lane_full;
           skip_samples = !(RT_DBG(fp) & 2u) && !__any(fc.lane_can & !fc.lane_full);
           if (fp.brute) { cand.lo = cand.hi = ~0ull; lane_lit = lane_dark = false; skip_samples = false; }   // RT_FLAG_BRUTE_FORCE
+          if (RT_DBG(fp) & 16777216u) { lane_lit = lane_dark = false; skip_samples = false; }   // audit build, bit 24: every pair through the exact walk
         }
         if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
         int n_wl = -1, n_wr = -1;
@@ -625,6 +627,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           if (!lane_lit && !lane_dark) atomicAdd(&C->dbg[2], 1ull);
           atomicAdd(&C->dbg[3], 1ull);
         }
+#ifdef RT_DEBUG_KERNEL
+        if ((RT_DBG(fp) & 33554432u) && active && !skip_samples && !(unc >= 0.0f) && !(LDS_SCENE && (lane_lit || (OPAQUE && lane_dark)))) {
+          // audit build, bit 25: a pair decided in fp32 against the exact walk of every cell (tests/test_gpu_audit.py)
+          double tsum = 0.0; int qd = 0;
+          for (int cell_ = 0; cell_ < n_cells; ++cell_) {
+            const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, cell_);
+            tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &qd, false, fp.plane_thr);
+          }
+          if (fabs(tsum - (double)total) > 1e-3 && atomicAdd(&C->dbg[3], 1ull) < 12ull) {
+            printf("[walk audit] level %d light %d prim %d: fp32 sum %.6f exact %.6f  p (%.17g %.17g %.17g) gpix %u\n", level, li, hits[h].prim, total, tsum, p.x, p.y, p.z, gpix);
+            for (int cell_ = 0; cell_ < n_cells; ++cell_) {
+              const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, cell_);
+              const double T_ = shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &qd, false, fp.plane_thr);
+              printf("[walk audit]    cell %d exact T %.6f dir (%.17g %.17g %.17g) maxdist %.17g\n", cell_, T_, er.dir.x, er.dir.y, er.dir.z, er.maxdist);
+            }
+          }
+        }
+#endif
         bool undecided = !skip_samples & (unc >= 0.0f);
         // the conservative claims of fan_cull are exact whatever the sample blocks computed for the lane
         if (LDS_SCENE && lane_lit) { total = (float)n_cells; undecided = false; }

@@ -60,3 +60,20 @@ def test_large_scene_culling_never_drops_a_crossed_record():
     crossings, dropped, frames = _audit_counts(p.stderr)
     print(f"45 randomised large scenes: {crossings} exact crossings over {frames} frames, {dropped} dropped")
     assert frames >= 45 and crossings > 10000 and dropped == 0, p.stderr[-2000:]
+
+
+def test_fp32_decided_pairs_agree_with_the_exact_walk():
+    """Audit build, RT_DEBUG_STATS bit 25: every (hit, light) pair that k_shade_fast decides in fp32 (not queued for the
+    re-test, not settled by the fully-lit / umbra shortcut) is evaluated again with the literal fp64 walk of every cell;
+    a pair whose sums differ by more than 1e-3 is printed.  Randomised small scenes (opaque and transparent, the ones
+    with more than 6 spheres / 2 planes / boxes go through k_shade_fast) and large ones: no line may appear.  Sharper
+    than the 8-bit image comparison: it sees a wrong decision even where the pixel does not change."""
+    if not os.path.exists(DEBUG_LIB):
+        pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
+    env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS=str(1 << 25))
+    for tool, args in (("random_fp32_survey.py", ["60"]), ("stress_accel.py", ["0", "12"])):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+        lines = [l for l in (p.stdout + p.stderr).splitlines() if l.startswith("[walk audit] level")]
+        print(f"{tool}: {len(lines)} fp32-decided pairs differ from the exact walk")
+        assert not lines, lines[:5]

@@ -28,7 +28,7 @@ hp = o + t * d
 p = hp + nrm * 1e-6
 f32 = np.float32
 U8 = f32(12 * 6.0e-8)
-jit = PixelKeyedJitter(1234)
+jit = PixelKeyedJitter(int(os.environ.get("RT_DIAG_SEED", "1234")))
 for li, L in enumerate(lights):
     tl = L.position - p; ldist = np.sqrt(tl @ tl); ld = tl / ldist
     ref = np.array([0, 1.0, 0]) if abs(ld[0]) >= 0.9 else np.array([1.0, 0, 0])
