@@ -30,6 +30,14 @@ def authored_scene_text(seed):
     if rng.random() < 0.3: lines.append("pln 1 0 0 -4 3")
     if rng.random() < 0.2: lines.append("pln 0 -1 0 -6 4")
     tops = {}                                                # column (x, z) -> current height
+    if seed % 5 == 4:                                        # large variant: a floor tiled with cubes (shared faces), > 128 surfaces
+        n_t = int(rng.integers(12, 20))
+        for ix in range(n_t):
+            for iz in range(n_t):
+                x, z = ix - n_t // 2 + 0.0, iz - n_t // 2 - 2.0
+                up_ = 1.0 if rng.random() < 0.08 else 0.0    # some tiles stand one unit proud
+                lines.append(f"box {x} {-0.5 + up_} {z} 1.0 {int(rng.integers(1, 5))}")
+                tops[(x, z)] = up_
     for _ in range(int(rng.integers(1, 9))):
         x, z = h(-3, 3), h(-3, 3)
         s = float(rng.choice([0.5, 1.0, 1.0, 2.0]))
