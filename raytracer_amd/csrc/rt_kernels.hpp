@@ -907,7 +907,7 @@ __global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp
       for (int cell = (int)member; cell < n_cells; cell += g) {
         const ExactRay er = exact_shadow_ray(sc, p, li, fp.n_shadow, fp.seed, rec.gpix, rec.level, cell);
         int queries = 0;
-        tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &queries, false, fp.plane_thr, &ac, cmask);
+        tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &queries, fp.sequential != 0, fp.plane_thr, &ac, cmask);
       }
       for (int o_ = g >> 1; o_ > 0; o_ >>= 1) tsum += __shfl_xor(tsum, o_);
     }

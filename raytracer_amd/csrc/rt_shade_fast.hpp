@@ -663,7 +663,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -l.x), fmaf(-2.0f * dn, nf.y, -l.y), fmaf(-2.0f * dn, nf.z, -l.z));
         const float rdv = fmaxf(dotf(rf, v), 0.0f);
         const float shin = (float)mat[9];
-        const float pw = (shin == 0.0f) ? 1.0f : (rdv > 0.0f ? powf(rdv, shin) : 0.0f);   // np.power(0, 0) == 1
+        // np.power(0, 0) == 1; the sequential renderer adds the specular term only for r.v > 0 (ray_tracer.py:356-359)
+        const float pw = rdv > 0.0f ? (shin == 0.0f ? 1.0f : powf(rdv, shin)) : ((shin == 0.0f && !fp.sequential) ? 1.0f : 0.0f);
         const float s2 = I * pw * (float)lg[6];
         spc[0] = fmaf((float)mat[3] * (float)lg[3], s2, spc[0]);
         spc[1] = fmaf((float)mat[4] * (float)lg[4], s2, spc[1]);

@@ -905,7 +905,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float rdv = fmaxf(dotf(rf, v), 0.0f);
       // rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals
       // (v_log_f32 / v_exp_f32, 1 ulp each; log2(0) = -inf -> 0); np.power(0, 0) == 1
-      const float pw = (shin == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
+      // (the sequential renderer adds the specular term only for r.v > 0, ray_tracer.py:356-359)
+      const float pw = (shin == 0.0f) ? ((fp.sequential && !(rdv > 0.0f)) ? 0.0f : 1.0f) : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
       const float s2 = I * pw * lg[6];
       spc0 = fmaf(ks0 * lg[3], s2, spc0);
       spc1 = fmaf(ks1 * lg[4], s2, spc1);

@@ -59,3 +59,29 @@ def test_sequential_rejects_numpy_stream():
     cam, st, mats, surfs, lights = load_scene(scene_path("pool.txt"), 2, 1)
     with pytest.raises(_lib.RtError):
         render(cam, st, mats, surfs, lights, 16, 16, jitter=("numpy", 1), verbose=False)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 4, 15, 18, 49, 52])
+def test_sequential_fp32_random_scenes(oracle, seed):
+    """Scenes of tools/sequential_survey.py that the fp32 kernels got wrong before they knew the sequential renderer's
+    specular rule (term only for r.v > 0, ray_tracer.py:356-359: with shininess 0 the vectorized renderer adds
+    Ks*Lc*1 where r.v = 0, the sequential one nothing — up to 240 levels on whole surfaces) and before the re-test
+    walk took the sequential walk's rules (no 20-step cap)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from test_gpu_random_scenes import random_scene_text
+    from test_gpu_many_spheres import many_spheres_text
+    from authored_survey import authored_scene_text
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.render import render_hip
+    kind = seed % 3
+    text = random_scene_text(7000 + seed, seed % 2 == 0) if kind == 0 else (authored_scene_text(seed) if kind == 1 else many_spheres_text(7 + seed % 10, 9000 + seed, seed % 2 == 1))
+    cam, st, objs = parse_scene_text(text)
+    mats, surfs, lights = separate_objects(objs)
+    ref = oracle.render(cam, st, mats, surfs, lights, 64, 48, jitter=("pixel", seed), sequential=True)
+    i64 = render_hip(cam, st, mats, surfs, lights, 64, 48, jitter=("pixel", seed), sequential=True, verbose=False)
+    i32 = render_hip(cam, st, mats, surfs, lights, 64, 48, jitter=("pixel", seed), sequential=True, precision="fp32", verbose=False)
+    assert (np.abs(i64 - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 1e-9
+    d8 = np.abs(_q(i32) - _q(ref))
+    print(f"seed {seed}: {len(surfs)} surfaces, sequential fp32 max 8-bit diff {d8.max()}")
+    assert d8.max() <= 1
