@@ -51,6 +51,7 @@ if __name__ == "__main__":
     bad = 0; worst = 0
     for seed in range(FIRST, FIRST + N):
         t0 = time.time()
+        if os.environ.get("RT_DEBUG_STATS"): print("seed", seed, flush=True)
         cam, st, objs = parse_scene_text(varied_text(seed))
         mats, surfs, lights = separate_objects(objs)
         W, H = 48, 36
