@@ -933,8 +933,13 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
     // the (hit, light) pairs the fp32 kernels could not decide within their error bounds: exact fp64 shadow terms
     Timed t(s, pf, 1);
     const int fgrid = FIX_QUEUES * std::max(1, s->num_cu * 4 / FIX_QUEUES);
-    if (lds) hipLaunchKernelGGL(k_fix_exact<true>, dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
-    else hipLaunchKernelGGL(k_fix_exact<false>, dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+    if (fp.sequential) {
+      if (lds) hipLaunchKernelGGL((k_fix_exact<true, true>), dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+      else hipLaunchKernelGGL((k_fix_exact<false, true>), dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+    } else {
+      if (lds) hipLaunchKernelGGL((k_fix_exact<true, false>), dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+      else hipLaunchKernelGGL((k_fix_exact<false, false>), dim3(fgrid), dim3(BLOCK), 0, s->stream, s->ds, fp, wb.fix, wb.counters, (float*)fb);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RT_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
 // code of the fp64 mode (soft_shadow_exact: same jitter, same walk), one lane per record.  The fp32 shade
 // kernels queue a pair whenever one of its hit / miss decisions lies within the error bound of their fp32
 // arithmetic (rt_shade_ls.hpp, rt_shade_fast.hpp), and shaded it with T = 0; the colour is linear in T.
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool SEQ>
 __global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp, const FixRec* __restrict__ fix,
                                                      Counters* C, float* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_SCENE ? LDS_PRIMS : 1];
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp
       for (int cell = (int)member; cell < n_cells; cell += g) {
         const ExactRay er = exact_shadow_ray(sc, p, li, fp.n_shadow, fp.seed, rec.gpix, rec.level, cell);
         int queries = 0;
-        tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &queries, fp.sequential != 0, fp.plane_thr, &ac, cmask);
+        tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &queries, SEQ, fp.plane_thr, &ac, cmask);
       }
       for (int o_ = g >> 1; o_ > 0; o_ >>= 1) tsum += __shfl_xor(tsum, o_);
     }

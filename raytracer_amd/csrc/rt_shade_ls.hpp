@@ -589,7 +589,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     // material terms of this hit in registers (fp32) for the light loop
     const float kd0 = (float)mat[0], kd1 = (float)mat[1], kd2 = (float)mat[2];
     const float ks0 = (float)mat[3], ks1 = (float)mat[4], ks2 = (float)mat[5];
-    const float shin = (float)mat[9];
+    // (the sequential renderer adds the specular term only for r.v > 0, ray_tracer.py:356-359: with shininess 0 the term
+    // is 1 for r.v > 0 and absent otherwise, which is what exp2(1e-30 * log2(r.v)) gives: 1, and 0 for log2(0) = -inf)
+    const float shin = ((float)mat[9] == 0.0f && fp.sequential) ? 1e-30f : (float)mat[9];
     const float one_m = 1.0f - (float)mat[10];
     // magnitude for the error bounds (LsTol): largest |oc|
     const float ocm = raw_sqrt(fmaxf(oc2max, 0.0f)) * 1.0001f;
@@ -905,8 +907,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float rdv = fmaxf(dotf(rf, v), 0.0f);
       // rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals
       // (v_log_f32 / v_exp_f32, 1 ulp each; log2(0) = -inf -> 0); np.power(0, 0) == 1
-      // (the sequential renderer adds the specular term only for r.v > 0, ray_tracer.py:356-359)
-      const float pw = (shin == 0.0f) ? ((fp.sequential && !(rdv > 0.0f)) ? 0.0f : 1.0f) : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
+      const float pw = (shin == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
       const float s2 = I * pw * lg[6];
       spc0 = fmaf(ks0 * lg[3], s2, spc0);
       spc1 = fmaf(ks1 * lg[4], s2, spc1);
