@@ -728,6 +728,12 @@ static int drain(rt_scene* s) {
     }
 #endif
 #ifdef RT_DEBUG_KERNEL
+    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 25))) {
+      unsigned long long w[8] = {0}, z[8] = {0};
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_walk_audit), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_walk_audit), z, sizeof z);
+      fprintf(stderr, "[rt debug] walk audit: %llu (hit, light) pairs decided in fp32 checked against the exact walk, %llu differ\n", w[0], w[1]);
+    }
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 23))) {
       unsigned long long w[8] = {0}, z[8] = {0};
       hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_fix_cause), sizeof w);

@@ -396,6 +396,7 @@ __device__ __forceinline__ rt_v2f bc_hi(rt_v2f a) { return __builtin_shufflevect
 // audit build: k_trace walk statistics (waves, wave-level / per-lane node steps, leaves, exact tests, cycles)
 __device__ unsigned long long g_walk_dbg[8];
 __device__ unsigned long long g_forced_cause[8]; // ... and which special case forced it (RT_UNC_FORCED tags)
+__device__ unsigned long long g_walk_audit[8];   // audit build, bit 25: [0] pairs k_shade_ls / k_shade_fast decided themselves and checked, [1] of them wrong
 __device__ unsigned long long g_fix_cause[8];    // k_shade_ls: why (hit, light) pairs went to the re-test queue (RT_DEBUG_STATS bit 23)
 __device__ unsigned long long g_pool_cyc[8];     // k_trace_pool wave cycles: refill, node steps, leaf bounds, exact tests, results, all, rounds
 __device__ __forceinline__ bool wave_first_active() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }

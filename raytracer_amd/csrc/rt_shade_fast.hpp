@@ -635,7 +635,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, cell_);
             tsum += shadow_walk(P, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &qd, false, fp.plane_thr);
           }
-          if (fabs(tsum - (double)total) > 1e-3 && atomicAdd(&C->dbg[3], 1ull) < 12ull) {
+          atomicAdd(&g_walk_audit[0], 1ull);
+          if (fabs(tsum - (double)total) > 1e-3 && atomicAdd(&g_walk_audit[1], 1ull) < 12ull) {
             printf("[walk audit] level %d light %d prim %d: fp32 sum %.6f exact %.6f  p (%.17g %.17g %.17g) gpix %u\n", level, li, hits[h].prim, total, tsum, p.x, p.y, p.z, gpix);
             for (int cell_ = 0; cell_ < n_cells; ++cell_) {
               const ExactRay er = exact_shadow_ray(sc, p, li, n_sh, fp.seed, gpix, (uint32_t)level, cell_);

@@ -885,6 +885,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       if (!lane_can) { total = (float)n_cells; undecided = false; }
       if (OPAQUE && lane_full) { total = 0.0f; undecided = false; }
       undecided &= active;
+#ifdef RT_DEBUG_KERNEL
+      if ((RT_DBG(fp) & 33554432u) && active && !undecided) {
+        // audit build, bit 25: every pair this kernel decides itself (sample loop or lit / umbra claim) against the
+        // literal fp64 walk of every cell (tests/test_gpu_audit.py)
+        const uint32_t t_ = threadIdx.x;
+        const d3 pe = mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS);
+        double tsum = 0.0; int qd = 0;
+        for (int cell_ = 0; cell_ < n_cells; ++cell_) {
+          const ExactRay er = exact_shadow_ray(sc, pe, li, fp.n_shadow, fp.seed, gpix, (uint32_t)level, cell_);
+          tsum += shadow_walk(sc.prims, sc.nS, sc.nP, sc.nB, sc.mats, er.so, er.dir, er.maxdist, &qd, false, fp.plane_thr);
+        }
+        atomicAdd(&g_walk_audit[0], 1ull);
+        if (fabs(tsum - (double)total) > 1e-3) {
+          if (atomicAdd(&g_walk_audit[1], 1ull) < 12ull)
+            printf("[walk audit] level %d light %d (k_shade_ls): fp32 sum %.6f exact %.6f  p (%.17g %.17g %.17g) gpix %u lane_can %d lane_full %d\n",
+                   level, li, total, tsum, pe.x, pe.y, pe.z, gpix, (int)lane_can, (int)lane_full);
+        }
+      }
+#endif
       if ((RT_DBG(fp) & (1u << 23)) && undecided) {      // audit build: why pairs go to the re-test queue
 #ifdef RT_DEBUG_KERNEL
         atomicAdd(&g_fix_cause[0], 1ull);

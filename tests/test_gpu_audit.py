@@ -63,14 +63,24 @@ def test_large_scene_culling_never_drops_a_crossed_record():
 
 
 def test_fp32_decided_pairs_agree_with_the_exact_walk():
-    """Audit build, RT_DEBUG_STATS bit 25: every (hit, light) pair that k_shade_fast decides in fp32 (not queued for the
-    re-test, not settled by the fully-lit / umbra shortcut) is evaluated again with the literal fp64 walk of every cell;
+    """Audit build, RT_DEBUG_STATS bit 25: every (hit, light) pair that k_shade_ls / k_shade_fast decide themselves (not
+    queued for the re-test; k_shade_ls: including its fully-lit / umbra claims) is evaluated again with the literal fp64
+    walk of every cell;
     a pair whose sums differ by more than 1e-3 is printed.  Randomised small scenes (opaque and transparent, the ones
     with more than 6 spheres / 2 planes / boxes go through k_shade_fast) and large ones: no line may appear.  Sharper
     than the 8-bit image comparison: it sees a wrong decision even where the pixel does not change."""
     if not os.path.exists(DEBUG_LIB):
         pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
     env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS=str(1 << 25))
+    # the headline kernel on the headline scene (1920x1080; the full 4K frame by hand: 54,853,298 pairs, 0 differ)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "pool4k", "--scale", "2", "--frames", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    found = re.findall(r"walk audit: (\d+) \(hit, light\) pairs decided in fp32 checked against the exact walk, (\d+) differ", p.stderr)
+    assert found, p.stderr[-2000:]
+    checked, differ = sum(int(a) for a, _ in found), sum(int(b) for _, b in found)
+    print(f"pool.txt 1920x1080: {checked} pairs decided by k_shade_ls checked against the exact walk, {differ} differ")
+    assert checked > 13000000 and differ == 0
     for tool, args in (("random_fp32_survey.py", ["60"]), ("stress_accel.py", ["0", "12"])):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
