@@ -371,7 +371,9 @@ static void free_workspace(rt_scene* s) {
 // 2e-6 of each other along a segment count ONCE; the fp32 kernels' product over all crossings counts both.  Between
 // different primitives that is systematic only where surfaces coincide: box faces on box faces or on a plane, duplicated
 // spheres / planes (tangent contacts are a set of measure zero).  One primitive of every such pair is marked here
-// (Prim::pad bit 0); a (hit, light) pair whose samples cross a marked primitive is left to the exact walk.
+// (Prim::pad bit 0); a (hit, light) pair whose samples cross a marked primitive is left to the exact walk.  A box with a
+// face in a plane gets bit 1: it only matters for samples that also cross a plane (boxes standing on a floor are the
+// normal case, shadow segments through the floor are not).
 static int mark_coincident(std::vector<Prim>& prims) {
   const double TOL = 2.5e-6;
   int marked = 0;
@@ -383,21 +385,39 @@ static int mark_coincident(std::vector<Prim>& prims) {
     for (size_t i = 0; i < prims.size(); ++i)
       if (prims[i].type == RT_BOX) { f.push_back({prims[i].a[ax], (int)i}); f.push_back({prims[i].a[3 + ax], (int)i}); }
     std::sort(f.begin(), f.end(), [](const Face& x, const Face& y) { return x.c < y.c; });
-    for (size_t i = 0; i < f.size(); ++i) {
-      Prim& A = prims[f[i].prim];
-      int budget = 4096;                      // many boxes on one level: give up on the pair tests and mark this one
-      for (size_t j = i + 1; j < f.size() && f[j].c - f[i].c <= TOL; ++j) {
-        if (f[j].prim == f[i].prim) continue;
-        if (--budget < 0) { mark(A); break; }
-        const Prim& B = prims[f[j].prim];
-        if (A.a[u] <= B.a[3 + u] + TOL && B.a[u] <= A.a[3 + u] + TOL && A.a[v] <= B.a[3 + v] + TOL && B.a[v] <= A.a[3 + v] + TOL) { mark(A); break; }
+    // groups of faces whose coordinates chain within TOL; inside a group a sweep along u keeps the faces whose
+    // u-interval reaches the current one (a floor of n tiles: one row of them), and those are compared in v
+    for (size_t g0 = 0; g0 < f.size();) {
+      size_t g1 = g0 + 1;
+      while (g1 < f.size() && f[g1].c - f[g1 - 1].c <= TOL) ++g1;
+      if (g1 - g0 >= 2) {
+        std::vector<Face> grp(f.begin() + g0, f.begin() + g1);
+        std::sort(grp.begin(), grp.end(), [&](const Face& x, const Face& y) { return prims[x.prim].a[u] < prims[y.prim].a[u]; });
+        std::vector<size_t> active;
+        long long budget = 64ll * (long long)grp.size() + 100000;      // pathological overlap: give up and mark
+        for (size_t i = 0; i < grp.size(); ++i) {
+          Prim& A = prims[grp[i].prim];
+          size_t w = 0;
+          for (size_t k = 0; k < active.size(); ++k)
+            if (prims[grp[active[k]].prim].a[3 + u] + TOL >= A.a[u]) active[w++] = active[k];
+          active.resize(w);
+          for (size_t k = 0; k < active.size(); ++k) {
+            const Face& fb = grp[active[k]];
+            if (fb.prim == grp[i].prim || std::fabs(fb.c - grp[i].c) > TOL) continue;
+            if (--budget < 0) { mark(A); break; }
+            const Prim& B = prims[fb.prim];
+            if (A.a[v] <= B.a[3 + v] + TOL && B.a[v] <= A.a[3 + v] + TOL) { mark(A); break; }
+          }
+          active.push_back(i);
+        }
       }
+      g0 = g1;
     }
     for (const Prim& pl : prims) {            // a box face lying in a plane
       if (pl.type != RT_PLANE || std::fabs(pl.a[ax]) < 1.0 - 1e-9) continue;
       const double c = pl.a[3] / pl.a[ax];
       for (Prim& b : prims)
-        if (b.type == RT_BOX && (std::fabs(b.a[ax] - c) <= TOL || std::fabs(b.a[3 + ax] - c) <= TOL)) mark(b);
+        if (b.type == RT_BOX && (std::fabs(b.a[ax] - c) <= TOL || std::fabs(b.a[3 + ax] - c) <= TOL) && !(b.pad & 2)) { b.pad |= 2; ++marked; }
     }
   }
   std::vector<Face> sp;

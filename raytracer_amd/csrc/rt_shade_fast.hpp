@@ -260,6 +260,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           // whole (hit, light) pair undecided (-> re-test queue).  ONE fp64 site per chunk instead of one per test site:
           // inlined behind every sample block the exact code cost 83 spilled VGPRs and 5 ms of a 22 ms frame.
           int dk0 = -1, dk1 = -1; uint32_t dm0 = 0u, dm1 = 0u;
+          bool plane_any = false;   // scenes with transparency: some sample of the chunk crosses a plane
           int ncross = 0;   // scenes with transparency: roots in range, any sample (the walk multiplies at most 20 crossings)
           auto retest = [&](int k_, uint32_t fmask) __attribute__((always_inline)) {
             if (fmask != 0u) {
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             }
             if (!OPAQUE) {
               ncross += (int)any1 + (int)any2;
-              if ((s_.pad & 1) && (any1 | any2)) unc = 1.0f;   // coincident surfaces: the walk counts two crossings once
+              // coincident surfaces: the walk counts two crossings once (bit 1: only together with a plane crossing)
+              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2)) unc = 1.0f;
             }
             retest(k_, fmask);
           };
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             }
             if (!OPAQUE) {
               ncross += (int)any1 + (int)any2;
-              if ((s_.pad & 1) && (any1 | any2)) unc = 1.0f;   // coincident surfaces: the walk counts two crossings once
+              // coincident surfaces: the walk counts two crossings once (bit 1: only together with a plane crossing)
+              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2)) unc = 1.0f;
             }
             retest(k_, fmask);
           };
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             if (!OPAQUE) {
               ncross += (int)any1;
               if ((s_.pad & 1) && any1) unc = 1.0f;
+              plane_any |= any1 | (fmask != 0u);
             }
             retest(k, fmask);
           }

@@ -120,3 +120,33 @@ def test_coincident_surfaces(oracle, tau, floor_tau, below):
     d8 = np.abs(_q(img32) - _q(ref))
     print(f"tau {tau} floor {floor_tau} below {below}: fp32 max 8-bit diff {d8.max()}, {(d8 > 1).sum()} channels > 1, {s32['retested']} of {3 * s32['hits']} pairs re-tested")
     assert d8.max() <= 1
+
+
+def test_many_tiles_and_boxes_on_a_floor(oracle):
+    """Scene creation's search for coincident faces on a floor of 40 x 40 transparent tiles (every side face shared)
+    plus 300 separate boxes standing on the floor plane (faces in a plane, nothing shared): correct image, and boxes
+    that merely stand on the plane do not send their shadow pairs to the exact walk."""
+    import time
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.render import render_hip
+    rng = np.random.default_rng(3)
+    head = ["cam 0 6 14 0 0.5 0 0 1 0 1.4 2", "set 0.2 0.25 0.3 2 2",
+            "mtl 0.8 0.8 0.8 0.3 0.3 0.3 0.1 0.1 0.1 10 0", "mtl 0.3 0.6 0.9 0.6 0.6 0.6 0.0 0.0 0.0 40 0.6",
+            "mtl 0.9 0.5 0.2 0.6 0.6 0.6 0.0 0.0 0.0 20 0.4"]
+    tail = ["sph 0 2.5 0 1.0 2", "lgt -6 9 5 1 1 1 1 0.9 1.0", "lgt 5 7 -4 0.7 0.7 0.6 1 0.8 0.0"]
+    tiles = head + ["pln 0 1 0 -1.5 1"] + [f"box {ix - 20 + 0.5} -0.25 {iz - 30 + 0.5} 1.0 {2 + (ix + iz) % 2}" for ix in range(40) for iz in range(40)] + tail
+    apart = head + ["pln 0 1 0 0 1"] + [f"box {(k % 20) * 1.5 - 15} 0.25 {(k // 20) * 1.5 - 16} 0.5 {2 + k % 2}" for k in range(300)] + tail
+    for name, lines in (("tiles", tiles), ("boxes apart", apart)):
+        cam, st, objs = parse_scene_text("\n".join(lines) + "\n")
+        mats, surfs, lights = separate_objects(objs)
+        ref = oracle.render(cam, st, mats, surfs, lights, 96, 64, jitter=("pixel", 2))
+        s32 = {}
+        t0 = time.time()
+        img = render_hip(cam, st, mats, surfs, lights, 96, 64, precision="fp32", jitter=("pixel", 2), stats=s32, verbose=False)
+        dt = time.time() - t0
+        d8 = np.abs(_q(img) - _q(ref))
+        frac = s32["retested"] / (2 * s32["hits"])
+        print(f"{name}: {len(surfs)} surfaces, fp32 max 8-bit diff {d8.max()}, {s32['retested']} of {2 * s32['hits']} pairs re-tested, scene + frame {dt:.2f} s")
+        assert d8.max() <= 1 and dt < 5.0
+        if name == "boxes apart":
+            assert frac < 0.2, frac
