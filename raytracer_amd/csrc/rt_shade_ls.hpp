@@ -790,7 +790,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float4* cells = s_cells + li * ((n_cells + 1) >> 1);
       str_act = act & s_lstr[li];
       if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
-      if (str_act != 0u) {
+      // scenes with transparency: the reference's walk multiplies at most 20 crossings (ray_tracer.py:257), the sample loop
+      // all of them — a (wave, light) whose candidate set could give a segment more than that goes to the exact walk
+      // (only the 12- / 16-sphere instantiations can get there; the sequential renderer's walk has no cap)
+      const bool over_cap = !OPAQUE && (2 * MAXS + MAXP + 2 * MAXB > WALK_CAP) && !fp.sequential &&
+                            2 * __popc(act & 0xFFFFu) + __popc((act >> 16) & 0xFFu) + 2 * nB > WALK_CAP;
+      if (str_act != 0u || over_cap) {
         // the light's sample square touches a candidate primitive: crossings at the sample end of a segment
         total = 0.0f; undecided = true;
       } else {
@@ -1001,9 +1006,6 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
                             hipStream_t st) {
   const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
   if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
-  // scenes with transparency: the reference's shadow walk multiplies at most 20 crossings (ray_tracer.py:257); this kernel
-  // forms the product over all of them, so it only serves scenes where no segment can cross more (k_shade_fast counts)
-  if (!opaque && !fp.sequential && 2 * ds.nS + ds.nP + 2 * ds.nB > WALK_CAP) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
