@@ -156,7 +156,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_frame* frame, v
  * pixel-keyed jitter; no RT_FLAG_TIMING; `out` is device memory.  The bounce queues take what the array has left
  * (>= 1.3 rays per pixel and level at the maximum size, more for smaller row sets); a frame that needs more fails
  * with RT_ERR_QUEUE_OVERFLOW — nothing is written out of bounds, and nothing is retried.  Blocks until the frame
- * is complete; with RT_FLAG_ASYNC (stats must be NULL) it only enqueues on the scene's stream.
+ * is complete; with RT_FLAG_ASYNC (stats must be NULL) it only enqueues on the scene's stream — that is the variant
+ * for HIP graph capture (the blocking one synchronises the stream, which a capture does not allow) — and the
+ * overflow of such a frame is reported by the next rt_sync() on the scene (the flags of the LAST async static frame
+ * before the sync: sync after each frame whose completeness matters).
  * All calls on one GPU share that GPU's array: calls of one process are serialised by the library, but an
  * RT_FLAG_ASYNC frame still in flight when the next call on the same GPU starts races with it (sync in between).
  */

@@ -347,6 +347,7 @@ struct rt_scene {
   // and a pinned counters block, so that the call itself allocates nothing
   unsigned char* static_scratch = nullptr;
   Counters* h_static = nullptr;
+  bool static_async = false;     // an RT_FLAG_ASYNC frame of rt_render_static has copied its counters to h_static since the last rt_sync
   std::mutex mu;
 };
 
@@ -443,6 +444,104 @@ static int mark_coincident(std::vector<Prim>& prims) {
   return marked;
 }
 
+// Scenes with transparency, fp32 mode, second kind of mark (Prim::pad bit 2).  Two crossings of DIFFERENT primitives
+// less than 2e-6 apart along a shadow segment also count once in the reference's walk (ray_tracer.py:279-291) — not only
+// on coincident faces (mark_coincident) but on every segment that passes the curve where two surfaces meet: the corner
+// line of floor and wall, the circle where a sphere is cut by a plane or another sphere, a sphere resting on a surface
+// (contact point).  Those are 1-dimensional sets of segments, so the fp32 kernels can test for them per SAMPLE: the
+// members of every pair of primitives whose surfaces come within NEAR_TOL of each other — and of which at least one
+// is not opaque (two opaque crossings: the first one already ends the walk with 0) — are marked here, and the kernels
+// compare the roots of the marked primitives a sample crosses (k_shade_fast, pair_roots); a sample with two of them within
+// 2e-6 + its fp32 error bound sends the (hit, light) pair to the exact walk.  Returns the number of primitives marked.
+static int mark_near_pairs(std::vector<Prim>& prims, const std::vector<double>& mats) {
+  const double TOL = 4e-6;
+  const size_t n = prims.size();
+  auto transparent = [&](const Prim& p) { return mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0; };
+  auto tol_of = [&](const Prim& a, const Prim& b) {
+    double m = 0.0;
+    for (int k = 0; k < 6; ++k) m = std::max(m, std::max(a.type == RT_PLANE && k < 3 ? 0.0 : std::fabs(a.a[k]), b.type == RT_PLANE && k < 3 ? 0.0 : std::fabs(b.a[k])));
+    return TOL + 1e-12 * m;
+  };
+  // do the SURFACES of a and b come within tol of each other?
+  auto near = [&](const Prim& a, const Prim& b, double tol) -> bool {
+    const Prim* x = &a; const Prim* y = &b;
+    if (x->type > y->type) std::swap(x, y);                       // (sphere, plane, box) order
+    if (x->type == RT_SPHERE && y->type == RT_SPHERE) {
+      const double dx = x->a[0] - y->a[0], dy = x->a[1] - y->a[1], dz = x->a[2] - y->a[2];
+      const double d = std::sqrt(dx * dx + dy * dy + dz * dz), r1 = std::fabs(x->a[3]), r2 = std::fabs(y->a[3]);
+      return d <= r1 + r2 + tol && d >= std::fabs(r1 - r2) - tol;
+    }
+    if (x->type == RT_SPHERE && y->type == RT_PLANE)
+      return std::fabs(x->a[0] * y->a[0] + x->a[1] * y->a[1] + x->a[2] * y->a[2] - y->a[3]) <= std::fabs(x->a[3]) + tol;
+    if (x->type == RT_SPHERE && y->type == RT_BOX) {
+      // |q - c| over the box surface ranges over [lo, hi]: hi = farthest corner; lo = distance to the solid box from
+      // outside, distance to the nearest face from inside
+      double out2 = 0.0, far2 = 0.0, inside_m = 1e300; bool inside = true;
+      for (int k = 0; k < 3; ++k) {
+        const double c = x->a[k], mn = std::min(y->a[k], y->a[3 + k]), mx = std::max(y->a[k], y->a[3 + k]);
+        if (c < mn) { out2 += (mn - c) * (mn - c); inside = false; }
+        else if (c > mx) { out2 += (c - mx) * (c - mx); inside = false; }
+        else inside_m = std::min(inside_m, std::min(c - mn, mx - c));
+        const double f = std::max(std::fabs(c - mn), std::fabs(c - mx)); far2 += f * f;
+      }
+      const double lo = inside ? inside_m : std::sqrt(out2), hi = std::sqrt(far2), r = std::fabs(x->a[3]);
+      return r >= lo - tol && r <= hi + tol;
+    }
+    if (x->type == RT_PLANE && y->type == RT_PLANE) {
+      const double d = x->a[0] * y->a[0] + x->a[1] * y->a[1] + x->a[2] * y->a[2];
+      if (std::fabs(d) < 1.0 - 1e-14) return true;                                  // they meet in a line
+      return std::fabs(x->a[3] - (d > 0 ? y->a[3] : -y->a[3])) <= tol;             // parallel: only when they coincide
+    }
+    if (x->type == RT_PLANE && y->type == RT_BOX) {
+      double mn = 1e300, mx = -1e300;
+      for (int c = 0; c < 8; ++c) {
+        const double v = x->a[0] * y->a[(c & 1) ? 3 : 0] + x->a[1] * y->a[(c & 2) ? 4 : 1] + x->a[2] * y->a[(c & 4) ? 5 : 2] - x->a[3];
+        mn = std::min(mn, v); mx = std::max(mx, v);
+      }
+      return mn <= tol && mx >= -tol;
+    }
+    // box, box: the solids overlap (within tol) and neither lies strictly inside the other
+    bool overlap = true, x_in_y = true, y_in_x = true;
+    for (int k = 0; k < 3; ++k) {
+      const double xl = std::min(x->a[k], x->a[3 + k]), xh = std::max(x->a[k], x->a[3 + k]);
+      const double yl = std::min(y->a[k], y->a[3 + k]), yh = std::max(y->a[k], y->a[3 + k]);
+      overlap &= xl <= yh + tol && yl <= xh + tol;
+      x_in_y &= xl > yl + tol && xh < yh - tol;
+      y_in_x &= yl > xl + tol && yh < xh - tol;
+    }
+    return overlap && !x_in_y && !y_in_x;
+  };
+  int marked = 0;
+  auto mark = [&](Prim& p) { if (!(p.pad & 4)) { p.pad |= 4; ++marked; } };
+  auto consider = [&](Prim& a, Prim& b) {
+    if ((a.pad & 4) && (b.pad & 4)) return;
+    if ((a.pad | b.pad) & 1) return;        // any crossing of a primitive marked by mark_coincident goes to the exact walk already
+    if (!transparent(a) && !transparent(b)) return;
+    if (near(a, b, tol_of(a, b))) { mark(a); mark(b); }
+  };
+  std::vector<int> planes, solids;
+  for (size_t i = 0; i < n; ++i) (prims[i].type == RT_PLANE ? planes : solids).push_back((int)i);
+  for (size_t i = 0; i < planes.size(); ++i) {
+    for (size_t j = i + 1; j < planes.size() && j < i + 4096; ++j) consider(prims[planes[i]], prims[planes[j]]);
+    for (int k : solids) consider(prims[planes[i]], prims[k]);
+  }
+  // spheres and boxes: sweep over the x-extent of their bounds
+  struct Ext { double lo, hi; int prim; };
+  std::vector<Ext> ext; ext.reserve(solids.size());
+  std::vector<BoxD> bx(n);
+  for (int k : solids) { bx[k] = prim_box(prims[k]); ext.push_back({bx[k].lo[0] - 2 * TOL, bx[k].hi[0] + 2 * TOL, k}); }
+  std::sort(ext.begin(), ext.end(), [](const Ext& a, const Ext& b) { return a.lo < b.lo; });
+  long long budget = 200000000ll;       // pathological overlap (everything on top of everything): mark the rest
+  for (size_t i = 0; i < ext.size(); ++i)
+    for (size_t j = i + 1; j < ext.size() && ext[j].lo <= ext[i].hi; ++j) {
+      if (--budget < 0) { mark(prims[ext[i].prim]); mark(prims[ext[j].prim]); continue; }
+      const BoxD &A = bx[ext[i].prim], &B = bx[ext[j].prim];
+      if (A.lo[1] > B.hi[1] + 2 * TOL || B.lo[1] > A.hi[1] + 2 * TOL || A.lo[2] > B.hi[2] + 2 * TOL || B.lo[2] > A.hi[2] + 2 * TOL) continue;
+      consider(prims[ext[i].prim], prims[ext[j].prim]);
+    }
+  return marked;
+}
+
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) try {
   if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null pointer");
   *out = nullptr;
@@ -535,7 +634,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
 
   bool any_transparent = false;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) any_transparent = true;
-  const int n_coincident = any_transparent ? mark_coincident(prims) : 0;
+  int n_coincident = any_transparent ? mark_coincident(prims) : 0;
+  if (any_transparent && !(getenv("RT_NEAR_PAIRS") && atoi(getenv("RT_NEAR_PAIRS")) == 0)) n_coincident += mark_near_pairs(prims, mats);
 
   rt_scene* s = new (std::nothrow) rt_scene();
   if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
@@ -802,6 +902,15 @@ static int drain(rt_scene* s) {
   return rc;
 }
 
+// A call that enqueued frames whose PendingFrame::user points into one of ITS OWN local arrays must not leave them
+// pending when it fails: the next drain would write through the dangling pointers.  Called on every error exit of
+// such a call (render_banded, rt_render_multi) with the scene's mutex held: the frames stay queued (their pinned
+// counter slot and events go back to the pools at the next drain), only their stats are no longer reported.
+static void forget_stats(rt_scene* s, const rt_stats* first, size_t n) {
+  for (PendingFrame& pf : s->pending)
+    if (pf.user >= first && pf.user < first + n) pf.user = nullptr;
+}
+
 extern "C" int rt_sync(rt_scene* s) try {
   if (!s) return fail(RT_ERR_INVALID, "rt_sync: null scene");
   std::lock_guard<std::mutex> lk(s->mu);
@@ -809,6 +918,15 @@ extern "C" int rt_sync(rt_scene* s) try {
   if (rc == RT_OK && s->sticky_overflow)      // an async frame's overflow that an internal drain (workspace growth) had to swallow
     rc = fail(RT_ERR_QUEUE_OVERFLOW, "an earlier RT_FLAG_ASYNC frame overflowed its bounce queues (they have been grown since): render it again");
   s->sticky_overflow = 0;
+  if (s->static_async) {
+    // RT_FLAG_ASYNC frames of rt_render_static copy their counters to h_static on the stream drain() has just waited
+    // for: the LAST such frame's overflow flags are reported here (earlier ones were overwritten: sync after each
+    // frame whose completeness matters).  That entry point cannot grow its queues, so there is nothing to retry with.
+    s->static_async = false;
+    if (rc == RT_OK && (s->h_static->overflow || s->h_static->overflow_fix))
+      rc = fail(RT_ERR_QUEUE_OVERFLOW, "an RT_FLAG_ASYNC frame of rt_render_static overflowed the static %s queue: its image is incomplete "
+                "(use rt_render, or render fewer rows per call)", s->h_static->overflow ? "bounce" : "re-test");
+  }
   return rc;
 } RT_CATCH_ALL
 
@@ -1206,12 +1324,34 @@ static int render_banded(rt_scene* s, const rt_camera* camera, const rt_frame* f
   std::vector<hipEvent_t> done((size_t)nb, nullptr);
   const DevCamera cam = to_dev_camera(camera);
   const WorkBufs wb = own_bufs(s);
+  // ONE failure path: bands already enqueued carry pointers into band_stats (a local) and wait on / are waited for by
+  // the copy stream, so a mid-loop error first lets both streams finish, forgets those stats pointers (the frames stay
+  // queued; the next drain returns their pinned slots and events), and returns this call's `done` events to the pool.
+  auto abort_call = [&](int code, PendingFrame* unqueued) {
+    const std::string msg = g_err;                       // (keep the first error's message)
+    hipStreamSynchronize(s->stream);
+    hipStreamSynchronize(s->copy_stream);
+    forget_stats(s, band_stats.data(), band_stats.size());
+    if (unqueued) {
+      for (EventPair& ep : unqueued->events) { s->event_pool.push_back(ep.a); s->event_pool.push_back(ep.b); }
+      if (unqueued->h_counters) s->h_slots.push_back(unqueued->h_counters);
+    }
+    for (hipEvent_t e : done) if (e) s->event_pool.push_back(e);
+    g_err = msg;
+    return code;
+  };
+#define BANDCHK(call, pfp)                                                                               \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) return abort_call(fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP,  \
+                                                 "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__), pfp); \
+  } while (0)
   for (int b = 0; b < nb; ++b) {
     rt_frame bf = *fr;
     bf.block_rows = band_rows; bf.n_parts = nb; bf.part = b;
     int32_t brows = 0;
     rc = rt_rows_in_part(bf.height, bf.block_rows, bf.part, bf.n_parts, &brows);
-    if (rc != RT_OK) return rc;
+    if (rc != RT_OK) return abort_call(rc, nullptr);
     if (nb == 1) { bf.n_parts = 1; bf.part = 0; bf.block_rows = 1; }
     const size_t off_px = (size_t)b * band_rows * fr->width, bval = (size_t)brows * fr->width * 3;
     PendingFrame pf;
@@ -1222,17 +1362,19 @@ static int render_banded(rt_scene* s, const rt_camera* camera, const rt_frame* f
     const FrameParams fp = make_params(&bf, brows, s->cap_queue, s->cap_hits, s->cap_fix);
     char* fb = (char*)s->d_fb + off_px * 3 * fsz;
     rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, &bf, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, &bf, (float*)fb, &pf);
-    if (rc != RT_OK) { s->h_slots.push_back(pf.h_counters); return rc; }
+    if (rc != RT_OK) return abort_call(rc, &pf);
     char* src = fb;
     if (!native) { src = (char*)s->d_out + off_px * 3 * esz; launch_convert(s, &pf, fb, fb_is_double, fr->out_format, src, bval); }
-    HIPCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+    BANDCHK(hipMemcpyAsync(pf.h_counters, s->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), &pf);
     done[(size_t)b] = get_event(s);
-    HIPCHK(hipEventRecord(done[(size_t)b], s->stream));
-    HIPCHK(hipStreamWaitEvent(s->copy_stream, done[(size_t)b], 0));
-    HIPCHK(hipMemcpyAsync((char*)out + off_px * 3 * esz, src, bval * esz, hipMemcpyDeviceToHost, s->copy_stream));
+    BANDCHK(hipEventRecord(done[(size_t)b], s->stream), &pf);
+    BANDCHK(hipStreamWaitEvent(s->copy_stream, done[(size_t)b], 0), &pf);
+    BANDCHK(hipMemcpyAsync((char*)out + off_px * 3 * esz, src, bval * esz, hipMemcpyDeviceToHost, s->copy_stream), &pf);
     s->pending.push_back(std::move(pf));
   }
+#undef BANDCHK
   rc = drain(s);                                   // waits for the render stream, folds the bands' counters
+  if (rc != RT_OK) forget_stats(s, band_stats.data(), band_stats.size());     // (a drain that failed half-way)
   hipError_t ce = hipStreamSynchronize(s->copy_stream);
   for (hipEvent_t e : done) if (e) s->event_pool.push_back(e);
   if (ce != hipSuccess) return fail(RT_ERR_HIP, "copy of the rendered bands failed: %s", hipGetErrorString(ce));
@@ -1396,8 +1538,8 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
   rc = fb_is_double ? launch_frame<double>(s, wb, cam, fp, fr, (double*)fb, &pf) : launch_frame<float>(s, wb, cam, fp, fr, (float*)fb, &pf);
   if (rc != RT_OK) return rc;
   if (!native) launch_convert(s, &pf, fb, fb_is_double, fr->out_format, out_device, nval);
-  if (fr->flags & RT_FLAG_ASYNC) return RT_OK;
   HIPCHK(hipMemcpyAsync(s->h_static, wb.counters, sizeof(Counters), hipMemcpyDeviceToHost, s->stream));
+  if (fr->flags & RT_FLAG_ASYNC) { s->static_async = true; return RT_OK; }      // overflow is reported by rt_sync
   HIPCHK(hipStreamSynchronize(s->stream));
   const Counters& c = *s->h_static;
   if (c.overflow_fix)
@@ -1417,6 +1559,9 @@ extern "C" int rt_render_static(rt_scene* s, const rt_camera* camera, const rt_f
 // Pinned host memory for output frames (hipHostMalloc): device -> host copies into it run at PCIe speed and
 // asynchronously; into pageable memory they are staged by the runtime at a fraction of that.
 // ------------------------------------------------------------------ rt_render_multi -----------
+static int render_multi_body(rt_scene* const* scenes, int n_scenes, const rt_camera* camera, const rt_frame* frame, void* out,
+                             int out_is_device, rt_stats* stats, std::vector<rt_stats>& st);
+
 extern "C" int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_camera* camera, const rt_frame* frame, void* out,
                                int out_is_device, rt_stats* stats) try {
   if (!scenes || n_scenes < 1 || !camera || !frame || !out) return fail(RT_ERR_INVALID, "rt_render_multi: null pointer or no scenes");
@@ -1424,9 +1569,32 @@ extern "C" int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_c
   for (int i = 0; i < n_scenes; ++i) if (!scenes[i]) return fail(RT_ERR_INVALID, "rt_render_multi: scenes[%d] is null", i);
   if (frame->jitter_mode != RT_JITTER_PIXEL_KEYED) return fail(RT_ERR_INVALID, "rt_render_multi: pixel-keyed jitter only (the numpy stream is consumed frame-wide)");
   if (frame->block_rows <= 0 || frame->width <= 0 || frame->height <= 0) return fail(RT_ERR_INVALID, "rt_render_multi: bad frame size / block_rows");
+  // The handles' async frames report into `st`, a local of this call: on EVERY failure (a handle that rejects the
+  // frame, runs out of memory growing its workspace, a failed copy) the frames the other handles still hold pending
+  // must forget those pointers before `st` goes away — the next drain on such a handle would otherwise write into
+  // freed memory (tests/test_gpu_multi.py: a failing handle, then a render on the surviving one).
+  std::vector<rt_stats> st((size_t)n_scenes);
+  int rc;
+  try { rc = render_multi_body(scenes, n_scenes, camera, frame, out, out_is_device, stats, st); }
+  catch (...) { rc = fail(RT_ERR_HIP, "rt_render_multi: internal error"); }
+  if (rc != RT_OK) {
+    const std::string msg = g_err;
+    for (int i = 0; i < n_scenes; ++i) {
+      rt_scene* s = scenes[i];
+      std::lock_guard<std::mutex> lk(s->mu);
+      hipSetDevice(s->device);
+      hipStreamSynchronize(s->stream);               // nothing of this call is still in flight when it returns
+      forget_stats(s, st.data(), st.size());
+    }
+    g_err = msg;
+  }
+  return rc;
+} RT_CATCH_ALL
+
+static int render_multi_body(rt_scene* const* scenes, int n_scenes, const rt_camera* camera, const rt_frame* frame, void* out,
+                             int out_is_device, rt_stats* stats, std::vector<rt_stats>& st) {
   const size_t esz = frame->out_format == RT_OUT_F64 ? 8 : (frame->out_format == RT_OUT_F32 ? 4 : 1);
   const size_t row_bytes = (size_t)frame->width * 3 * esz, block_bytes = row_bytes * (size_t)frame->block_rows;
-  std::vector<rt_stats> st((size_t)n_scenes);
   std::vector<int32_t> rows((size_t)n_scenes, 0);
   std::vector<rt_frame> fr((size_t)n_scenes, *frame);
   // 1. every handle renders its rows into its own tile buffer, all at once
@@ -1448,6 +1616,9 @@ extern "C" int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_c
         s->cap_tile = need;
       }
     }
+    // fault injection for tests/test_gpu_multi.py: RT_TEST_FAIL_HANDLE=i makes handle i refuse its part of the frame
+    // while the handles before it already hold their async frames pending
+    if (const char* e = getenv("RT_TEST_FAIL_HANDLE")) if (atoi(e) == i) return fail(RT_ERR_INVALID, "rt_render_multi: failure of handle %d injected by RT_TEST_FAIL_HANDLE", i);
     rc = rt_render(s, camera, &fr[i], s->d_tile, 1, &st[i]);
     if (rc != RT_OK) return rc;
   }
@@ -1503,7 +1674,7 @@ extern "C" int rt_render_multi(rt_scene* const* scenes, int n_scenes, const rt_c
     *stats = t;
   }
   return RT_OK;
-} RT_CATCH_ALL
+}
 
 extern "C" int rt_host_alloc(size_t bytes, void** out) try {
   if (!out) return fail(RT_ERR_INVALID, "rt_host_alloc: null pointer");

@@ -25,7 +25,8 @@ struct __attribute__((aligned(16))) Prim {
   int32_t mat;   // 0-based material index
   int32_t orig;  // index in the original surface list
   int32_t type;
-  int32_t pad;   // bit 0: a surface of this primitive coincides with another primitive's, bit 1: a box face lies in a plane (rt_api.hip, mark_coincident)
+  int32_t pad;   // bit 0: a surface of this primitive coincides with another primitive's, bit 1: a box face lies in a plane (rt_api.hip, mark_coincident),
+                 // bit 2: its surface meets / touches another primitive's and one of the two is not opaque (mark_near_pairs)
 };
 static_assert(sizeof(Prim) == 64, "Prim must be 64 bytes");
 

@@ -51,6 +51,63 @@ constexpr int LEAF_LIST = 20, CAND_LIST = 16;   // per-lane lists of the large-s
 // (WAVE_LEAF_CAP, rt_device.hpp: leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves)
 constexpr int WAVE_REC_CAP = 128;     // records a (wave, light) list holds; more: the lanes test their leaves' bounds themselves     // leaves a (wave, light) list holds; more: the lanes walk the hierarchy themselves
 
+// Scenes with transparency: the crossings of ONE marked primitive (Prim::pad bit 2, rt_api.hip mark_near_pairs) by a
+// shadow segment — direction (dx, dy, dz), unit to a few ulp, from the exact shadow origin p — with a bound on the fp32
+// error of each root.  Used only to find two DIFFERENT primitives' crossings closer than the 2e-6 the reference's walk
+// needs to tell them apart (ray_tracer.py:279-291); t < 0: no such root.  Same arithmetic as the sample blocks above.
+struct PairRoots { float t0, t1, e0, e1; };
+__device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, float dy, float dz) {
+  constexpr float U8 = 12.0f * 6.0e-8f, U1 = 6.0e-8f;
+  PairRoots r; r.t0 = r.t1 = -1.0f; r.e0 = r.e1 = 0.0f;
+  if (s_.type == 0) {
+    const double ocx = p.x - s_.a[0], ocy = p.y - s_.a[1], ocz = p.z - s_.a[2];
+    const float cc = (float)(((ocx * ocx + ocy * ocy) + ocz * ocz) - s_.a[4]);
+    const float r_ = (float)s_.a[3];
+    const float ocn = raw_sqrt(fmaxf(cc + r_ * r_, 0.0f));
+    const float e_b = U8 * ocn, kap = 4.0f * e_b, kap0 = 4.0f * e_b * e_b + 4.0f * U1 * fabsf(cc);
+    const float b = fmaf((float)ocz, dz, fmaf((float)ocy, dy, (float)ocx * dx));
+    const float disc = fmaf(b, b, -cc);
+    const float bound = fmaf(kap, fabsf(b), kap0);
+    if (disc > bound) {                                   // (grazing samples are deferred to fp64 by the sample block: not here)
+      const float sq = raw_sqrt(disc);
+      const float t1 = b < 0.0f ? sq - b : -b - sq;       // the root that does not cancel
+      const float e1 = e_b + bound * raw_rcp(sq) + 4.0f * U1 * fabsf(t1);
+      const float t2 = cc * raw_rcp(t1);
+      r.t0 = t1; r.e0 = e1;
+      r.t1 = t2; r.e1 = fabsf(t2) * (e1 * raw_rcp(fabsf(t1)) + 4.0f * U1);
+    }
+  } else if (s_.type == 1) {
+    const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
+    const float den = fmaf((float)s_.a[2], dz, fmaf((float)s_.a[1], dy, (float)s_.a[0] * dx));
+    if (fabsf(den) > 2.0f * U8) {
+      const float t = num * raw_rcp(den);
+      r.t0 = t; r.e0 = fabsf(t) * (1.5f * U8 * raw_rcp(fabsf(den)) + 4.0f * U1);
+    }
+  } else {
+    const float jx = raw_rcp(dx), jy = raw_rcp(dy), jz = raw_rcp(dz);
+    const float ax = (float)(s_.a[0] - p.x) * jx, bx = (float)(s_.a[3] - p.x) * jx;
+    const float ay = (float)(s_.a[1] - p.y) * jy, by = (float)(s_.a[4] - p.y) * jy;
+    const float az = (float)(s_.a[2] - p.z) * jz, bz = (float)(s_.a[5] - p.z) * jz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
+    const float rel = 2.0f * fmaf(U8, jm, 4.0f * U1);
+    if (tn <= tf + rel * (fabsf(tn) + fabsf(tf)) && jm <= 1e3f) {
+      r.t0 = tn; r.e0 = rel * fabsf(tn);
+      r.t1 = tf; r.e1 = rel * fabsf(tf);
+    }
+  }
+  return r;
+}
+// Do two primitives' crossings of one segment (length md) come closer than the walk's 2e-6 (+ 25 % and the fp32 bounds)?
+__device__ __forceinline__ bool pair_close(const PairRoots& a, const PairRoots& b, float md) {
+  const float top = fmaf(md, 1.0001f, 1e-5f);
+  auto one = [&](float ta, float ea, float tb, float eb) __attribute__((always_inline)) {
+    return (ta > 0.0f) & (tb > 0.0f) & (ta < top) & (tb < top) & (fabsf(ta - tb) <= 2.5e-6f + ea + eb);
+  };
+  return one(a.t0, a.e0, b.t0, b.e0) | one(a.t0, a.e0, b.t1, b.e1) | one(a.t1, a.e1, b.t0, b.e0) | one(a.t1, a.e1, b.t1, b.e1);
+}
+
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCENE && CH <= 9) ? 2 : 1))) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
@@ -262,6 +319,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           int dk0 = -1, dk1 = -1; uint32_t dm0 = 0u, dm1 = 0u;
           bool plane_any = false;   // scenes with transparency: some sample of the chunk crosses a plane
           int ncross = 0;   // scenes with transparency: roots in range, any sample (the walk multiplies at most 20 crossings)
+          // scenes with transparency: the marked primitives (Prim::pad bit 2: their surface meets another primitive's) that some
+          // sample of this chunk crosses; two of them in one sample may be closer than 2e-6 -> compared after the chunk's primitives
+          int pk0 = -1, pk1 = -1, pk2 = -1, pk3 = -1, npk = 0;
+          auto note_marked = [&](int k_, bool crossed, bool deferred) __attribute__((always_inline)) {
+            if (deferred) unc = 1.0f;              // a decision of a marked primitive left to fp64: the walk sorts it out
+            else if (crossed) {
+              if (npk == 0) pk0 = k_; else if (npk == 1) pk1 = k_; else if (npk == 2) pk2 = k_; else if (npk == 3) pk3 = k_; else unc = 1.0f;
+              ++npk;
+            }
+          };
           auto retest = [&](int k_, uint32_t fmask) __attribute__((always_inline)) {
             if (fmask != 0u) {
               if (dk0 < 0) { dk0 = k_; dm0 = fmask; }
@@ -314,9 +381,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
             if (!OPAQUE) {
-              ncross += (int)any1 + (int)any2;
+              // (samples deferred to the fp64 decision may cross as well: counted as if they did)
+              ncross += fmask != 0u ? 2 : (int)any1 + (int)any2;
               // coincident surfaces: the walk counts two crossings once (bit 1: only together with a plane crossing)
-              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2)) unc = 1.0f;
+              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2 | (fmask != 0u))) unc = 1.0f;
+              if (s_.pad & 4) note_marked(k_, any1 | any2, fmask != 0u);
             }
             retest(k_, fmask);
           };
@@ -364,9 +433,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!OPAQUE) { any1 |= in1; any2 |= in2; }
             }
             if (!OPAQUE) {
-              ncross += (int)any1 + (int)any2;
+              // (samples deferred to the fp64 decision may cross as well: counted as if they did)
+              ncross += fmask != 0u ? 2 : (int)any1 + (int)any2;
               // coincident surfaces: the walk counts two crossings once (bit 1: only together with a plane crossing)
-              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2)) unc = 1.0f;
+              if (((s_.pad & 1) | ((s_.pad & 2) && plane_any)) && (any1 | any2 | (fmask != 0u))) unc = 1.0f;
+              if (s_.pad & 4) note_marked(k_, any1 | any2, fmask != 0u);
             }
             retest(k_, fmask);
           };
@@ -394,8 +465,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (!OPAQUE) any1 |= in1;
             }
             if (!OPAQUE) {
-              ncross += (int)any1;
-              if ((s_.pad & 1) && any1) unc = 1.0f;
+              ncross += (int)(any1 | (fmask != 0u));
+              if ((s_.pad & 1) && (any1 | (fmask != 0u))) unc = 1.0f;
+              if (s_.pad & 4) note_marked(k, any1, fmask != 0u);
               plane_any |= any1 | (fmask != 0u);
             }
             retest(k, fmask);
@@ -622,6 +694,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             if (dm0 == 0u) { dk0 = dk1; dm0 = dm1; dk1 = -1; dm1 = 0u; }
           }
           if (!OPAQUE && ncross > WALK_CAP && !fp.sequential) unc = 1.0f;   // a sample may cross more surfaces than the walk visits
+          if (!OPAQUE && __any((npk >= 2) & (npk <= 4) & !(unc >= 0.0f))) {
+            // merged crossings (see pair_roots): per sample, the roots of every two marked primitives the chunk crosses.
+            // Rare (segments through the neighbourhood of an intersection curve), so the sample's direction is formed
+            // again here instead of indexing the register arrays above with a run-time sample number.
+            if ((npk >= 2) & (npk <= 4) & !(unc >= 0.0f)) {
+              bool close = false;
+              for (int s = 0; s < CH && c * CH + s < n_cells; ++s) {
+                const int cellidx = c * CH + s;
+                f3 ts = tl;
+                if (n_sh > 1) {
+                  const int i = cellidx / n_sh, j = cellidx - i * n_sh;
+                  const float oi = fmaf(jit_ui(key, (uint32_t)cellidx), cell, fmaf(cell, (float)i, half));
+                  const float oj = fmaf(jit_uj(key, (uint32_t)cellidx), cell, fmaf(cell, (float)j, half));
+                  ts = mkf(fmaf(oj, up.x, fmaf(oi, right.x, tl.x)), fmaf(oj, up.y, fmaf(oi, right.y, tl.y)),
+                           fmaf(oj, up.z, fmaf(oi, right.z, tl.z)));
+                }
+                const float d2 = dotf(ts, ts), rinv = raw_rsq(d2), mds = d2 * rinv;
+                const float sx = ts.x * rinv, sy = ts.y * rinv, sz = ts.z * rinv;
+                for (int ia = 0; ia + 1 < npk; ++ia) {
+                  const int ka = ia == 0 ? pk0 : (ia == 1 ? pk1 : pk2);
+                  const PairRoots A = pair_roots(P[ka], p, sx, sy, sz);
+                  for (int ib = ia + 1; ib < npk; ++ib) {
+                    const int kb = ib == 1 ? pk1 : (ib == 2 ? pk2 : pk3);
+                    close |= pair_close(A, pair_roots(P[kb], p, sx, sy, sz), mds);
+                  }
+                }
+              }
+              if (close) unc = 1.0f;
+            }
+          }
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
         }

@@ -68,3 +68,36 @@ def test_multi_device_output_fp32_and_u8(oracle):
         hip.hipFree(buf)
         for gs in scenes:
             gs.close()
+
+
+def test_a_failing_handle_leaves_the_others_usable(monkeypatch):
+    """handle 1 fails while handle 0 already holds its async frame pending with a pointer into the call's
+    local stats array; the call must not leave that pointer behind (the next drain on handle 0 would write through it)."""
+    from raytracer_amd import _lib, load_scene
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene, render_multi
+    W, H = 96, 64
+    cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"), 2, 3)
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    scenes = [GpuScene(packed) for _ in range(3)]
+    try:
+        good, s_good = render_multi(scenes, cam, W, H, 2, 3, precision="fp64", jitter=3)
+        good = good.copy()
+        monkeypatch.setenv("RT_TEST_FAIL_HANDLE", "2")
+        for _ in range(3):
+            with pytest.raises(_lib.RtError) as ei:
+                render_multi(scenes, cam, W, H, 2, 3, precision="fp64", jitter=3)
+            assert "injected" in str(ei.value)
+            junk = [np.full(4096, 7.0) for _ in range(8)]        # churn the host heap where the dead stats array lived
+            for gs in scenes:
+                single = gs.render(cam, W, H, 2, 3, precision="fp64", jitter=3)   # drains whatever the failed call left pending
+                assert rel_err(single, good).max() < 1e-12
+                assert gs.last_stats["rays"] == s_good["rays"]
+            assert all(float(j[0]) == 7.0 and float(j.sum()) == 7.0 * 4096 for j in junk)
+        monkeypatch.delenv("RT_TEST_FAIL_HANDLE")
+        again, s_again = render_multi(scenes, cam, W, H, 2, 3, precision="fp64", jitter=3)
+        assert rel_err(again, good).max() < 1e-12 and s_again["rays"] == s_good["rays"]
+    finally:
+        for gs in scenes:
+            gs.close()

@@ -1,0 +1,73 @@
+"""Merged crossings (round 3): the reference's shadow walk steps 1e-6 past a crossing and accepts the next one only
+beyond another 1e-6 (ray_tracer.py:279-291), so two crossings of DIFFERENT primitives less than 2e-6 apart count once —
+on every shadow segment that passes the curve where two surfaces meet (room corner line, a sphere cut by a plane or
+resting on it).  The fp32 kernels' product over crossings counted both: round 2's `tools/authored_survey.py` found
+6 of 1,800 grid-aligned scenes with 1-21 channels off by 2-25 levels (DESIGN.md "known residue").
+Those scenes are the fixtures tests/golden/residue/authored_<seed>.txt (text of tools/authored_survey.authored_scene_text
+(seed), inputs only); expected output = the oracle's render of the same scene.  Every channel must be within one level."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = [37, 53, 285, 585, 1005, 1027]
+
+
+def _load(seed):
+    from raytracer_amd import parse_scene_text, separate_objects
+    with open(os.path.join(GOLDEN, "residue", f"authored_{seed}.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    return (cam, st) + tuple(separate_objects(objs))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_authored_residue_scene_fp32_within_one_level(oracle, seed):
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    cam, st, mats, surfs, lights = _load(seed)
+    W, H = 80, 60                                    # the survey's frame: the failing samples are sets of measure zero
+    ref, ost = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), return_stats=True)
+    s32 = {}
+    img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", stats=s32, verbose=False)
+    d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+    assert all(s32[k] == ost[k] for k in ("rays", "hits", "shadow_rays"))
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+    i64 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp64", verbose=False)
+    assert (np.abs(i64 - ref) / np.maximum(np.abs(ref), 1e-12)).max() < 1e-9
+
+
+def test_corner_line_and_contact_point_by_construction(oracle):
+    """Hand-made: a transparent floor and a transparent wall seen from below/behind, with an un-jittered light placed so
+    that the single shadow ray of a whole diagonal of pixels runs exactly through the corner line; plus a transparent
+    sphere resting on the floor seen through the floor (contact point) and two intersecting transparent spheres."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    text = """cam 0 -3 7  0 1 0  0 1 0  1.2 2
+set 0.2 0.25 0.3 1 3
+mtl 0.6 0.6 0.6 0.5 0.5 0.5 0.0 0.0 0.0 10 0.5
+mtl 0.8 0.3 0.2 0.5 0.5 0.5 0.2 0.2 0.2 30 0.6
+mtl 0.2 0.4 0.8 0.5 0.5 0.5 0.0 0.0 0.0 0 0.0
+pln 0 1 0 0 1
+pln 0 0 1 -4 1
+pln 0 1 0 -6 3
+sph 1.0 1.0 0.0 1.0 2
+sph 2.2 1.0 0.5 1.0 2
+sph -2.0 0.5 1.0 0.5 2
+lgt 0 4 4 0.9 0.9 0.9 1 0.9 0.0
+lgt -4 6 2 0.5 0.6 0.9 1 0.7 1.0
+"""
+    cam, st, objs = parse_scene_text(text)
+    mats, surfs, lights = separate_objects(objs)
+    for (W, H, n_sh) in ((96, 72, 1), (96, 72, 3)):
+        st.root_number_shadow_rays = n_sh
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 7))
+        s32 = {}
+        img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 7), precision="fp32", stats=s32, verbose=False)
+        d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+        assert d8.max() <= 1, f"n_shadow {n_sh}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+        assert 0 < s32["retested"] < s32["hits"] * len(lights)          # the exact walk is the exception, not the rule

@@ -99,3 +99,65 @@ def test_static_entry_rejects_what_it_cannot_serve():
                 big.free()
     finally:
         buf.free()
+
+
+def test_static_entry_runs_under_graph_capture_and_reports_async_overflow():
+    """hipMemGetInfo cannot see a hipMalloc paired with a hipFree, pinned allocations or event creation.  A stream
+    capture in GLOBAL mode can: any allocation, synchronisation or event creation inside the captured region invalidates
+    the capture and the call fails.  The async static frame is captured, replayed twice and compared with rt_render;
+    then an async static frame that must overflow its queues is reported by rt_sync (it used to be lost)."""
+    import torch
+    from raytracer_amd import _lib, load_scene
+    from raytracer_amd.render import GpuScene
+    dev = torch.device("cuda", 0)
+    cam, st, mats, surfs, lights = load_scene(scene_path("original.txt"), 3, 4)
+    W, H = 120, 72
+    cam.setup(W / H)
+    ref = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
+    out = torch.full((H, W, 3), -7.0, dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream(dev)
+    with GpuScene.from_objects(mats, surfs, lights, st.background_color) as gs:
+        gs.render(cam, W, H, 3, 4, precision="fp64", jitter=5, out_ptr=ref.data_ptr())
+        ref_stats = dict(gs.last_stats)
+        gs.render(cam, W, H, 3, 4, precision="fp64", jitter=5, out_ptr=out.data_ptr(), static=True)      # (first use outside the capture)
+        assert gs.last_stats["rays"] == ref_stats["rays"]
+        out.fill_(-7.0)
+        torch.cuda.synchronize()
+        gs.set_stream(stream.cuda_stream)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="global"):
+            gs.render(cam, W, H, 3, 4, precision="fp64", jitter=5, out_ptr=out.data_ptr(), static=True, flags=_lib.RT_FLAG_ASYNC)
+        torch.cuda.synchronize()
+        assert float(out.min()) == -7.0                       # captured, not executed
+        for _ in range(2):
+            out.fill_(-7.0)
+            g.replay()
+            torch.cuda.synchronize()
+            assert float(((out - ref).abs() / ref.abs().clamp_min(1e-12)).max()) < 1e-12
+        del g
+        gs.set_stream(None)
+        gs.sync()                                             # the captured frame's counters: no overflow
+    # An async static frame that cannot fit: the camera sits inside a sphere that is transparent AND reflective, so every
+    # pixel's hit spawns two children: level 1 holds 2 rays per pixel, the static queues ~1.3 at the maximum row-set size.
+    from raytracer_amd import parse_scene_text, separate_objects
+    text = """cam 0 0 0  0 0 1  0 1 0  1 2
+set 0.2 0.3 0.4 1 3
+mtl 0.5 0.5 0.5 1 1 1 0.5 0.5 0.5 10 0.5
+sph 0 0 0 10 1
+lgt 0 5 0 1 1 1 1 0.5 1
+"""
+    cam2, st2, objs = parse_scene_text(text)
+    mats2, surfs2, lights2 = separate_objects(objs)
+    cam2.setup(512 / 256)
+    big = torch.empty((256 * 512 * 3,), dtype=torch.float32, device=dev)
+    with GpuScene.from_objects(mats2, surfs2, lights2, st2.background_color) as gs:
+        with pytest.raises(_lib.RtError) as ei:
+            gs.render(cam2, 512, 256, 1, 3, precision="fp32", jitter=5, out_ptr=big.data_ptr(), static=True)
+        assert ei.value.code == _lib.RT_ERR_QUEUE_OVERFLOW
+        gs.render(cam2, 512, 256, 1, 3, precision="fp32", jitter=5, out_ptr=big.data_ptr(), static=True, flags=_lib.RT_FLAG_ASYNC)
+        with pytest.raises(_lib.RtError) as ei:
+            gs.sync()                                         # used to return RT_OK with an incomplete image
+        assert ei.value.code == _lib.RT_ERR_QUEUE_OVERFLOW
+        gs.sync()                                             # reported once
+        gs.render(cam2, 512, 256, 1, 3, precision="fp32", jitter=5, out_ptr=big.data_ptr())      # rt_render grows and retries
+        assert gs.last_stats["level_rays"][1] == 2 * 512 * 256
