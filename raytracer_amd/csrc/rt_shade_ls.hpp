@@ -58,6 +58,24 @@ __device__ __forceinline__ v2f pk_rcp(v2f a) { v2f r; r.x = raw_rcp(a.x); r.y = 
 __device__ __forceinline__ bool in_open(float u, float hi) { return __float_as_uint(u) < __float_as_uint(hi); }
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
 
+// A 16-byte LDS read that is REALLY issued one loop iteration ahead.  Written in C++ ("nb = cells[q + 1]" at the top of
+// the iteration, consumed at the top of the next one), hipcc moves the read to where its value is used: the loop then
+// starts every iteration with ds_read_b128 + s_waitcnt lgkmcnt(0), a full LDS latency with two waves per SIMD to hide
+// it (seen in the ISA of round 2's loops).  lds_issue starts the read, lds_arrive waits for it; between the two the
+// compiler treats the destination as already written, so nothing may touch it — the "+v" of lds_arrive orders every use
+// behind the wait.  (LDS returns in order and the loop has no other LDS / scalar-memory access, so the compiler's own
+// waitcnt bookkeeping stays conservative.)
+typedef float ls_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_issue(ls_v4f& dst, const float4* p) {
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float4*)p;
+  // "+v": destination tied to the variable's current register — the loop-carried variable then lives in ONE register
+  // quadruple, and no copy can be placed between the issue and the wait (with "=v" hipcc put the result in a fresh
+  // quadruple and copied it to the loop's register right behind the ds_read, before the data had arrived).  Call it
+  // after the last use of the previous value.
+  asm volatile("ds_read_b128 %0, %1" : "+v"(dst) : "v"(a));
+}
+__device__ __forceinline__ void lds_arrive(ls_v4f& dst) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dst)); }
+
 constexpr int LS_MAX_CELLS = 1024;   // lights x n^2 entries of the per-block sample table (8 KiB)
 constexpr int LS_MAX_LIGHTS = 16;    // lights / materials staged in LDS (uniform global loads inside the
 constexpr int LS_MAX_MATS = 32;      // light loop were emitted as vector loads + full-latency waits)
@@ -142,7 +160,8 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
   }
   // cell base offsets: LDS broadcast reads, fetched one iteration ahead (with ~2 waves per SIMD an
   // un-prefetched ds_read + s_waitcnt at the top of every pair stalls the wave for its full latency)
-  float4 nb = cells[0];                                                     // (b0.x, b1.x, b0.y, b1.y) of sample pair 0
+  ls_v4f nb = {0.0f, 0.0f, 0.0f, 0.0f};                                     // (b0.x, b1.x, b0.y, b1.y) of sample pair 0
+  lds_issue(nb, cells);
   uint32_t xa = key.a + JIT_PHI_A, xb = key.b + JIT_PHI_B;                  // cell 0 (see jit_ui / jit_uj)
 #pragma unroll 1
   for (int q = 0; q < n_pairs; ++q) {
@@ -154,11 +173,12 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     for (int k = 0; k < MAXP; ++k) { asm("" : "+v"(D01[k])); asm("" : "+v"(D2n[k])); }
     const int c0 = 2 * q, c1 = 2 * q + 1;
     const bool valid1 = c1 < n_cells;                                       // wave-uniform
-    const float4 bq = nb;
-    nb = cells[q + 1 < n_pairs ? q + 1 : 0];
+    lds_arrive(nb);
     v2f oi, oj;                                                             // ray_tracer.py:224-225
-    oi.x = fmaf((float)xa, cell32, bq.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, bq.y);
-    oj.x = fmaf((float)xb, cell32, bq.z); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, bq.w);
+    oi.x = fmaf((float)xa, cell32, nb.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, nb.y);
+    oj.x = fmaf((float)xb, cell32, nb.z); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, nb.w);
+    asm volatile("" : "+v"(oi), "+v"(oj));                                  // (oi, oj are complete before the next read overwrites nb)
+    lds_issue(nb, cells + (q + 1 < n_pairs ? q + 1 : 0));                   // the next pair's offsets, in flight during this iteration
     xa += 2u * JIT_PHI_A; xb += 2u * JIT_PHI_B;                             // jitter lattice of the next pair
     const v2f d2 = pk_fma(oi, splat(T1) + oi, pk_fma(oj, splat(T2) + oj, splat(T0)));   // |ts|^2
     uint32_t m0 = 0xFFFFFFFFu, m1 = valid1 ? 0xFFFFFFFFu : 0u;             // min of candidate bit patterns
@@ -324,9 +344,95 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
     if (OPAQUE) n_blocked += (uint32_t)(m0 < __float_as_uint(d2.x)) + (uint32_t)(m1 < __float_as_uint(d2.y));
     else total += tr.x + (valid1 ? tr.y : 0.0f);
   }
+  lds_arrive(nb);                                                           // (the read issued by the last iteration)
   fl.unc = unc; fl.mlow = mlow; fl.dmin = dmin;
   if (OPAQUE) total = (float)(2 * n_pairs - (int)n_blocked);
   return total;
+}
+
+// The same sum for the usual configuration of an all-opaque scene, WITHOUT square roots or reciprocals: every active
+// sphere has the shadow origin outside it (or is the hit's own sphere) and every sample of the light outside it.
+// Along p + tau*ts the sphere's quadratic is f(tau) = |ts|^2 tau^2 + 2 (oc.ts) tau + cc with f(0) = cc >= 0 and
+// f(1) > 0, so the segment crosses the sphere iff both roots lie in (0, 1): a positive discriminant and the vertex
+// -(oc.ts)/|ts|^2 inside (0, 1) —
+//        blocked  <=>  min( bt^2 - |ts|^2 cc,  -bt,  bt + |ts|^2 ) > 0        (bt = oc.ts; one v_min3_f32 per sample)
+// (the hit's own sphere, cc = +0: roots 0 and -2bt/|ts|^2; the far one is in (0, 1) iff bt < 0, given f(1) > 0 — the
+// same expression).  A plane: 0 < num/den < 1  <=>  min(num den, den^2 - num den) > 0.  The maximum of those minima
+// over the primitives is positive iff the sample is blocked: 11 full-rate instructions per (sample pair, sphere)
+// instead of 12 of which two are v_sqrt_f32 (quarter rate), and no rcp for the planes.  The only decision that can
+// come within its fp32 error bound is the sign of the discriminant (tracked as before, LsFlags::unc) and a segment
+// parallel to a plane (LsFlags::dmin): bt = 0 or bt = -|ts|^2 with a positive discriminant would need cc < 0 or
+// f(1) < 0.  The caller checks the preconditions per (wave, light) and uses ls_light_sum otherwise.
+template <int NS, int MAXP, bool SDENSE, bool NOPLANES>
+__device__ __forceinline__ float ls_light_sum_simple(v2f (&AB)[NS], v2f (&Cc)[NS], const float (&kapS)[NS], v2f (&D01)[MAXP], v2f (&D2n)[MAXP],
+                                                     uint32_t act, const float4* __restrict__ cells, int n_cells, JitKey key, float cell32,
+                                                     float T0, LsFlags& fl) {
+  const int n_pairs = (n_cells + 1) >> 1;
+  float unc = fl.unc, dmin = fl.dmin;
+  v2f blocked = mk2(0.0f, 0.0f);                                            // blocked samples, counted in floats (see below)
+  v2f big; big.x = 8.507059173e37f;                                         // 2^126 (.y is never read: op_sel broadcast)
+  ls_v4f nb = {0.0f, 0.0f, 0.0f, 0.0f};
+  // loop control kept to a pointer, a counter and a branch: in the one- and two-sphere instantiations, which shade most
+  // of a frame's penumbra lanes, 12 scalar instructions per iteration (next-entry select, padding-sample select, counters)
+  // were a third of the 28 + 12 instructions a wave issues per sample pair.  The table has an entry behind the last pair
+  // (read ahead, never used); the padding sample of an odd grid has NaN offsets in the table: every quantity of that
+  // sample is NaN, v_min3 / v_max3 ignore NaN operands (IEEE minNum / maxNum), and clamp(NaN) = 0 — it counts as
+  // unblocked without a select, so the sum below starts from n_cells, not from 2 n_pairs
+  const float4* cp = cells;
+  lds_issue(nb, cp);
+  uint32_t xa = key.a + JIT_PHI_A, xb = key.b + JIT_PHI_B;
+#pragma unroll 1
+  for (int q = n_pairs; q > 0; --q) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { asm("" : "+v"(AB[k])); asm("" : "+v"(Cc[k])); }      // keeps the op_sel broadcasts in the loop (see ls_light_sum)
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) { asm("" : "+v"(D01[k])); asm("" : "+v"(D2n[k])); }
+    lds_arrive(nb);
+    v2f oi, oj;                                                             // ray_tracer.py:224-225
+    oi.x = fmaf((float)xa, cell32, nb.x); oi.y = fmaf((float)(xa + JIT_PHI_A), cell32, nb.y);
+    oj.x = fmaf((float)xb, cell32, nb.z); oj.y = fmaf((float)(xb + JIT_PHI_B), cell32, nb.w);
+    asm volatile("" : "+v"(oi), "+v"(oj));                                  // (complete before the next read overwrites nb)
+    ++cp;
+    lds_issue(nb, cp);
+    xa += 2u * JIT_PHI_A; xb += 2u * JIT_PHI_B;
+    // |ts|^2 = |tl|^2 + oi^2 + oj^2: right and up are perpendicular to tl by construction (ray_tracer.py:207-213); the
+    // 2 oi (tl.right) + 2 oj (tl.up) of the fp32 basis is below 3e-7 |oi| |tl|, i.e. < 1e-7 relative with the light
+    // farther than 3 RL — inside the 54 u the discriminant's bound allows for |ts|^2 cc (LsTol)
+    const v2f d2 = pk_fma(oi, oi, pk_fma(oj, oj, splat(T0)));
+    v2f W;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {                                          // spheres: sphere.py:49-71
+      if (!SDENSE && !(act & (1u << k))) continue;
+      const v2f bt = pk_fma(oj, lo2(Cc[k]), pk_fma(oi, hi2(AB[k]), lo2(AB[k])));         // oc.ts
+      const v2f disc = pk_fma(bt, bt, -(d2 * hi2(Cc[k])));
+      const v2f s = bt + d2;
+      unc = fmaxf(fmaxf(unc, fmaf(kapS[k], fabsf(bt.x), -fabsf(disc.x))), fmaf(kapS[k], fabsf(bt.y), -fabsf(disc.y)));
+      const float w0 = fminf(fminf(disc.x, -bt.x), s.x), w1 = fminf(fminf(disc.y, -bt.y), s.y);
+      if (SDENSE && first) { W.x = w0; W.y = w1; first = false; }           // (compile time: no initial value to fold in)
+      else { if (first) { W = mk2(-1.0f, -1.0f); first = false; } W.x = fmaxf(W.x, w0); W.y = fmaxf(W.y, w1); }
+    }
+    if (first) W = mk2(-1.0f, -1.0f);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {                                        // planes: infinite_plane.py:30-42
+      if (!NOPLANES && (act & (0x10000u << k))) {
+        const v2f den = pk_fma(oj, lo2(D2n[k]), pk_fma(oi, hi2(D01[k]), lo2(D01[k])));   // N.ts
+        const v2f x = hi2(D2n[k]) * den;                                    // num den
+        const v2f y = pk_fma(den, den, -x);
+        dmin = fminf(dmin, fminf(fabsf(den.x), fabsf(den.y)));
+        W.x = fmaxf(W.x, fminf(x.x, y.x)); W.y = fmaxf(W.y, fminf(x.y, y.y));
+      }
+    }
+    // blocked <=> W > 0, counted without compares: clamp(W * 2^126) is exactly 1 for every normal W > 0 and exactly 0 for
+    // W <= 0 or NaN (one v_pk_mul_f32 with the clamp bit + one v_pk_add_f32 for the two samples); a denormal W > 0 would
+    // add a fraction — the caller treats a sum that is not a whole number as undecided
+    v2f ind;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] clamp" : "=v"(ind) : "v"(W), "v"(big));
+    blocked += ind;
+  }
+  lds_arrive(nb);                                                           // (the read issued by the last iteration)
+  fl.unc = unc; fl.dmin = dmin;
+  return (float)n_cells - (blocked.x + blocked.y);
 }
 
 #ifndef LS_WAVES
@@ -395,10 +501,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const int li = e / n_pairs_, q_ = e - li * n_pairs_;
         const float radius = (float)sc.lights[LIGHT_STRIDE * li + 8];
         const float cell = radius / (float)n_side, half = -0.5f * radius;
-        const int c0_ = 2 * q_, c1_ = 2 * q_ + 1 < n_cells ? 2 * q_ + 1 : 0;
+        const bool pad = 2 * q_ + 1 >= n_cells;           // the second sample of an odd grid's last pair: NaN offsets (see ls_light_sum_simple)
+        const int c0_ = 2 * q_, c1_ = pad ? 0 : 2 * q_ + 1;
         const int i0 = c0_ / n_side, j0 = c0_ - i0 * n_side, i1 = c1_ / n_side, j1 = c1_ - i1 * n_side;
-        s_cells[e] = n_sh > 1 ? make_float4(fmaf(cell, (float)i0, half), fmaf(cell, (float)i1, half), fmaf(cell, (float)j0, half), fmaf(cell, (float)j1, half))
-                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float nan_ = __uint_as_float(0x7FC00000u);
+        s_cells[e] = n_sh > 1 ? make_float4(fmaf(cell, (float)i0, half), pad ? nan_ : fmaf(cell, (float)i1, half), fmaf(cell, (float)j0, half), pad ? nan_ : fmaf(cell, (float)j1, half))
+                              : make_float4(0.0f, pad ? nan_ : 0.0f, 0.0f, pad ? nan_ : 0.0f);
       }
     }
     for (int li = threadIdx.x; li < sc.nL; li += BLOCK) {
@@ -543,6 +651,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
     uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
     float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
+    uint32_t bad_cc = 0u;                         // spheres the shadow origin is inside of, or whose surface it lies on without being the hit's own (ls_light_sum_simple's precondition)
     float a_sgn[MAXS];
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
@@ -559,6 +668,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         near_scene &= fabsf(cc) < 1000.0f * (float)s_.a[4];
         oc2max = fmaxf(oc2max, cc + (float)s_.a[4]);
         if (own == k) { own_in_bit = cc < 0.0f ? 1u << k : 0u; own_out_bit = cc < 0.0f ? 0u : 1u << k; }
+        bad_cc |= ((cc < 0.0f) | ((own != k) & (cc < 1e-4f * (float)s_.a[4]))) ? 1u << k : 0u;
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -687,6 +797,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
             const float A_ = dotf(oc, tl), cc_ = a_Cc[k].y, r = sf.w;
             a_AB[k].x = A_;
+            if (brute) continue;                 // RT_FLAG_BRUTE_FORCE: every primitive is tested for every sample, nothing to decide here
             const float qb = A_ - r * RL;
             const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
             const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), cc_);
@@ -734,6 +845,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             const f3 N = mkf(nf4.x, nf4.y, nf4.z);
             const float D0_ = dotf(N, tl), num_ = a_D2n[k].y;
             a_D01[k].x = D0_;
+            if (brute) continue;
             // |N.right| + |N.up| <= sqrt2 |N - (N.ld) ld|, N unit (to 0.1 %)
             const float nperp2 = fmaxf(fmaf(-D0_ * rT0, D0_, 1.002f), 0.0f);
             const float spread = hw2 * raw_sqrt(nperp2) + 1e-6f * fabsf(D0_);
@@ -809,7 +921,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const float tlen = T0 * rl;                                            // |tl|
         const float tsm = tlen + RL;
         const float e_b = 1.5f * LS_U * ocm * (9.0f * tsm + 25.0f * RL);
-        tol.kap = 2.0f * e_b + 51.0f * LS_U * ocm * tsm;
+        tol.kap = 2.0f * e_b + 54.0f * LS_U * ocm * tsm;      // (51 u + 3 u for |ts|^2 without its tl.right / tl.up terms, ls_light_sum_simple)
         {
           // the same bound with each sphere's own |oc| = sqrt(cc + r^2) instead of the largest one (a grazed sphere is
           // usually a near one: 3-5x fewer undecided pairs on the pool scene), never below 1e-3 of it
@@ -828,6 +940,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         tol.elo = 2.0f * T_LO * tsm + 2.0f * (e_b + tol.kap);
         tol.eden = 12.0f * LS_U * tsm;
         LsFlags fl = ls_flags_init();
+        // all-opaque scenes without boxes: the square-root-free loop when every candidate sphere has the wave's shadow origins
+        // outside it (or is the hit's own) and the light's samples outside it (ls_light_sum_simple); wave-uniform
+        const bool simple = OPAQUE && MAXB == 0 && !lo_path && !(RT_DBG(fp) & 64u) && ((act & 0xFFFFu & s_lin[li]) == 0u) &&
+                            !__any(active & ((bad_cc & act) != 0u));
         if (lo_path)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                      T0, T1, T2, tol.kap, fl, own);
@@ -851,7 +967,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
           }
           const uint32_t act2 = (act & ~((1u << MAXS) - 1u)) | ((1u << j) - 1u);
           const bool nopl = ((act >> 16) & 0xFFu) == 0u;
-          if (j == 2) {
+          if (simple) {
+            if (j == 2)
+              total = nopl ? ls_light_sum_simple<2, MAXP, true, true>(gAB, gCc, gkap, a_D01, a_D2n, act2, cells, n_cells, key, cell32, T0, fl)
+                           : ls_light_sum_simple<2, MAXP, true, false>(gAB, gCc, gkap, a_D01, a_D2n, act2, cells, n_cells, key, cell32, T0, fl);
+            else if (j == 1)
+              total = nopl ? ls_light_sum_simple<1, MAXP, true, true>(reinterpret_cast<v2f(&)[1]>(gAB), reinterpret_cast<v2f(&)[1]>(gCc), reinterpret_cast<float(&)[1]>(gkap), a_D01, a_D2n, act2, cells, n_cells, key, cell32, T0, fl)
+                           : ls_light_sum_simple<1, MAXP, true, false>(reinterpret_cast<v2f(&)[1]>(gAB), reinterpret_cast<v2f(&)[1]>(gCc), reinterpret_cast<float(&)[1]>(gkap), a_D01, a_D2n, act2, cells, n_cells, key, cell32, T0, fl);
+            else      // planes only
+              total = ls_light_sum_simple<1, MAXP, false, false>(reinterpret_cast<v2f(&)[1]>(gAB), reinterpret_cast<v2f(&)[1]>(gCc), reinterpret_cast<float(&)[1]>(gkap), a_D01, a_D2n, act2, cells, n_cells, key, cell32, T0, fl);
+          } else if (j == 2) {
             LsPrims<2, MAXP, MAXB, OPAQUE> pr2{gAB, gCc, gSg, gtau, gkap, a_D01, a_D2n, a_tauP, a_blo, a_bhi, a_tauB, a_binside};
             total = nopl ? ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false, true, true>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl)
                          : ls_light_sum<2, 2, MAXP, MAXB, OPAQUE, false, true, false>(pr2, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl);
@@ -864,6 +989,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             else      // planes / boxes only
               total = ls_light_sum<1, 1, MAXP, MAXB, OPAQUE, false>(pr1, act2, nB, cells, n_cells, key, cell32, tl, right, up, T0, T1, T2, tol.kap, fl);
           }
+        } else if (simple) {
+          // (every sphere slot active — the brute-force frames, scenes of exactly MAXS spheres in a row —: no per-slot test)
+          const bool dense = (act & ((1u << MAXS) - 1u)) == ((1u << MAXS) - 1u), nopl = ((act >> 16) & 0xFFu) == 0u;
+          total = dense ? (nopl ? ls_light_sum_simple<MAXS, MAXP, true, true>(a_AB, a_Cc, a_kapS, a_D01, a_D2n, act, cells, n_cells, key, cell32, T0, fl)
+                                : ls_light_sum_simple<MAXS, MAXP, true, false>(a_AB, a_Cc, a_kapS, a_D01, a_D2n, act, cells, n_cells, key, cell32, T0, fl))
+                        : ls_light_sum_simple<MAXS, MAXP, false, false>(a_AB, a_Cc, a_kapS, a_D01, a_D2n, act, cells, n_cells, key, cell32, T0, fl);
         } else
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, false>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                       T0, T1, T2, tol.kap, fl);
@@ -871,7 +1002,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // to |tl|, which the bounds assume)
         // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
         const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
-        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far;
+        // (ls_light_sum_simple counts blocked samples in floats: a sum that is not a whole number had a denormal decision value)
+        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far | (simple & (total != floorf(total)));
         if (RT_DBG(fp) & (1u << 23))    // cause bits: 1 grazing discriminant, 2 root at the origin, 4 parallel plane, 8 light close, 16 far
           dbg_cause = ((!(fl.unc < -tol.kap0) && fl.unc < 3.0e38f) ? 1u : 0u) | (fl.unc >= 3.005e38f ? (32u << (int)((fl.unc - 3.005e38f) * 1e-36f)) : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
                       (((T0 < 9.0f * RL * RL) | !(T0 > 1e-12f)) ? 8u : 0u) | (far ? 16u : 0u);

@@ -1,16 +1,17 @@
 #!/bin/bash
 # PMC passes for the frame kernels (run on the GPU box).  One counter group per rocprofv3 run
 # (rocprofv3 does not split counters over passes; gfx950 limits: 8 SQ, 4 TCC, 2 GRBM per run).
-#   tools/profile_pmc.sh [workload] [outdir]
+#   tools/profile_pmc.sh [workload] [outdir] [extra quick_bench.py arguments, e.g. --brute]
 set -u
 WL=${1:-pool4k}
 OUT=${2:-/root/repo/gpurun_out/pmc_$WL}
+EXTRA=${3:-}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-    python3 /root/repo/tools/quick_bench.py "$WL" --frames 3 > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+    python3 /root/repo/tools/quick_bench.py "$WL" --frames 3 $EXTRA > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY &&

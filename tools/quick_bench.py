@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare a 1/4-size frame with the oracle")
     ap.add_argument("--n-shadow", type=int, default=None, help="override the shadow-ray root (cost breakdowns)")
     ap.add_argument("--depth", type=int, default=None, help="override the recursion cap")
+    ap.add_argument("--brute", action="store_true", help="RT_FLAG_BRUTE_FORCE frames: every surface tested for every shadow sample (the flop model's work; "
+                                                         "the run profiles/r03_*_brute_kernel_stats.csv comes from)")
     args = ap.parse_args()
     cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
     W //= args.scale; H //= args.scale
@@ -46,7 +48,7 @@ def main():
         best = None
         for f in range(args.frames):
             t0 = time.perf_counter()
-            img = gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, flags=_lib.RT_FLAG_TIMING)
+            img = gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, flags=_lib.RT_FLAG_TIMING | (_lib.RT_FLAG_BRUTE_FORCE if args.brute else 0))
             wall = (time.perf_counter() - t0) * 1e3
             s = gs.last_stats
             if best is None or s["total_ms"] < best["total_ms"]:
@@ -54,7 +56,7 @@ def main():
         flops = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
                                    hits=best["hits"], segments=max(best["segments"], 0))
         rays = best["rays"] + best["shadow_rays"]
-        out = {"workload": desc if args.scale == 1 else f"{desc} /{args.scale}", "frame_ms": round(best["total_ms"], 3),
+        out = {"workload": (desc if args.scale == 1 else f"{desc} /{args.scale}") + (" [RT_FLAG_BRUTE_FORCE]" if args.brute else ""), "frame_ms": round(best["total_ms"], 3),
                "shade_ms": round(best["shade_ms"], 3), "trace_ms": round(best["trace_ms"], 3), "other_ms": round(best["other_ms"], 3),
                "Mrays_per_s": round(rays / best["total_ms"] / 1e3, 1),
                "shade_TFLOPs": round(flops / best["shade_ms"] / 1e9, 2),
