@@ -1024,9 +1024,15 @@ struct Timed {   // RAII-ish helper: bracket one launch with events when timing 
 };
 
 template <typename FB>
-static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, const FrameParams& fp, const rt_frame* fr,
+static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, const FrameParams& fp_in, const rt_frame* fr,
                         FB* fb, PendingFrame* pf) {
   const bool lds = s->ds.n <= LDS_PRIMS;
+  // fp32 frames of scenes k_shade_ls serves: level 0 is ONE kernel (camera ray -> nearest hit -> shading per lane; see
+  // k_shade_ls, `fused`), no k_trace launch and no hit list for the 75 % of a frame's hits that are camera-ray hits.
+  // RT_FUSE0=0 keeps the two-kernel level 0 (A/B).
+  FrameParams fp = fp_in;
+  const bool ls_kernel = fr->precision == RT_FP32 && lds && s->shade_variant == 0 && s->n_coincident == 0 && shade_ls_serves(s->ds, fp);
+  fp.fuse0 = (ls_kernel && !(getenv("RT_FUSE0") && atoi(getenv("RT_FUSE0")) == 0)) ? 1u : 0u;
   const int grid = s->num_cu * 8;
   RayQueue q[2] = {make_queue(wb, 0), make_queue(wb, 1)};
   const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
@@ -1041,7 +1047,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
     }
     if (tgrid < 1) tgrid = 1;
     if (sgrid < 1) sgrid = 1;
-    {
+    if (!(level == 0 && fp.fuse0)) {
       Timed t(s, pf, 0);
       if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
       else if (level >= 1 && s->pool_trace) hipLaunchKernelGGL((k_trace_pool<FB>), dim3(s->num_cu * 4), dim3(BLOCK), 0, s->stream, s->ds, fp, level, cur, wb.hits, wb.counters, fb);
@@ -1299,6 +1305,7 @@ static FrameParams make_params(const rt_frame* fr, int32_t rows, size_t cap_queu
   fp.plane_thr = fp.sequential ? std::nextafter(1e-6, 0.0) : 1e-6;   // infinite_plane.py:20 (t < 1e-6 misses) vs :42 (t > 1e-6 hits)
   fp.fix_cap = (uint32_t)std::min<size_t>(cap_fix / FIX_QUEUES, 0x03FFFFFFu);
   fp.brute = (fr->flags & RT_FLAG_BRUTE_FORCE) ? 1u : 0u;
+  fp.fuse0 = 0u;
   return fp;
 }
 

@@ -268,6 +268,42 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
   return best;
 }
 
+// nearest() for a wave of COHERENT unit-direction rays over a small scene (the fused level 0 of k_shade_ls: an 8x8 pixel
+// tile of camera rays): same result, but a sphere's exact fp64 test (~70 instruction slots with its square root and two
+// divisions) runs only when some lane of the wave can hit it by a conservative fp32 test — the discriminant
+// (oc.d)^2 - (|oc|^2 - r^2) with a margin of 1e-5 (|oc|^2 + r^2), two orders of magnitude above its fp32 rounding.  A
+// skipped sphere has an exactly negative discriminant for every lane (t = INF), which changes neither the minimum nor
+// the (t, orig) tie rule.  Must be called convergently (wave-level vote).
+__device__ __forceinline__ double nearest_coherent(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out, double plane_thr) {
+  double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  int k = 0;
+  for (int e = nS; k < e; ++k) {
+    const double ox = o.x - P[k].a[0], oy = o.y - P[k].a[1], oz = o.z - P[k].a[2];
+    const float fx = (float)ox, fy = (float)oy, fz = (float)oz, r2 = (float)P[k].a[4];
+    const float oc2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+    const float b = fmaf(fz, dz, fmaf(fy, dy, fx * dx));
+    const bool maybe = !(fmaf(b, b, r2 - oc2) < -1e-5f * (oc2 + r2));          // (NaN / inf: tested exactly)
+    if (!__any(maybe)) continue;
+    double t = RT_INF;
+    if (maybe) t = sphere_t(P[k], o, d);
+    const int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  for (int e = nS + nP; k < e; ++k) {
+    double t = plane_t(P[k], o, d, plane_thr);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  for (int e = nS + nP + nB; k < e; ++k) {
+    double t = box_hit<false>(P[k], o, d, nullptr);
+    int og = P[k].orig;
+    if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
+  }
+  *k_out = bk;
+  return best;
+}
+
 // Stackless walk of the hierarchy by one lane.  node_hit(node) / prim_may(bound) are the
 // conservative tests of the query, on_prim(k) runs the exact code for record k.  The walk is
 // latency-bound (every step depends on a load), so the successor of a hit node is fetched

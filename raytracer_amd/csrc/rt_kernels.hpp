@@ -99,6 +99,7 @@ struct FrameParams {
   double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
   uint32_t fix_cap;      // capacity of ONE re-test sub-queue (FixRec); sub-queue q starts at fix[q * fix_cap]
   uint32_t brute;        // RT_FLAG_BRUTE_FORCE: fp32 kernels test every surface for every shadow sample (no culling, no shortcuts)
+  uint32_t fuse0;        // level 0 of k_shade_ls traces its own camera rays (no k_trace launch, no hit list): set per launch by launch_frame
 };
 
 __device__ __forceinline__ uint32_t global_pixel(const RowSet& rs, uint32_t lp) {
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_SCENE
           t = nearest_accel<true>(P, sc.nS, sc.nP, ac, r.o, r.d, &k, fp.plane_thr, s_wleaves + (threadIdx.x >> 6) * (LDS_SCENE ? 0 : WAVE_LEAF_CAP), try_wave);
         } else {
           r = load_ray(level, slot, cam, fp.rs, q);
-          t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &ac);
+          // (camera rays of a small scene: the wave's rays are coherent, most spheres are missed by all of them)
+          if (LDS_SCENE && level == 0) t = nearest_coherent(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr);
+          else t = nearest(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k, fp.plane_thr, &ac);
         }
         hit = active && k >= 0;
         if (active) {

@@ -468,7 +468,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   const int n_side = n_sh > 1 ? n_sh : 1;
   const int n_cells = n_side * n_side;
   const bool brute = fp.brute != 0u;
-  if (C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
+  // Level 0 fused with the nearest-hit query (fp.fuse0, LDS-resident scenes; ray_tracer.py:491-519 shades a batch right
+  // after its query too): a chunk is 64 pixels — an 8x8 tile —, every lane forms its camera ray, runs the literal fp64
+  // nearest() over the staged records and shades its own hit.  No k_trace launch, no 16-byte HitRec per pixel written and
+  // read back, no global load at the start of a chunk; pixels that miss get the background here.
+  const bool fused = level == 0 && fp.fuse0 != 0u;
+  if (!fused && C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
   {
     const int words = sc.n * (int)(sizeof(Prim) / 16);
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
@@ -546,8 +551,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   const int nS = sc.nS, nP = sc.nP, nB = sc.nB;
   float umbra_t0_max = 3.0e38f;                              // 1000 * (smallest sphere radius)^2
   for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
-  uint32_t count = C->n_hits[level];
+  uint32_t count = fused ? C->n_rays[0] : C->n_hits[level];
   if (count > fp.hit_cap) count = fp.hit_cap;
+  uint32_t fused_hits = 0u;                                  // hits of this wave's chunks (fused level 0): one atomic per wave at the end
   const float inv_cells = 1.0f / (float)n_cells;
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   }
   while (chunk != 0xFFFFFFFFu) {
     const uint32_t h = chunk * 64u + lane;
-    const bool active = h < count;
+    bool active = h < count;
     long long ck_t = prof ? clock64() : 0;
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
     v2f a_AB[MAXS], a_Cc[MAXS], a_Sg[(MAXS + 1) / 2];
@@ -615,9 +621,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     int mat_idx = 0, own = -1;
     bool own_is_plane = false;
     uint32_t lp = 0, gpix = 0;
+    HitRec hr; hr.slot = h; hr.prim = 0; hr.t = 0.0;
+    RayIn r; r.o = r.d = r.w = mk3(0, 0, 0); r.lp = 0;
+    if (fused) {
+      // (the idle lanes of the frame's last chunk trace a copy of its last pixel: nearest_coherent votes per wave)
+      r = load_ray(0, active ? h : count - 1u, cam, fp.rs, q);
+      int k_ = -1;
+      hr.t = nearest_coherent(P, nS, nP, nB, r.o, r.d, &k_, fp.plane_thr);
+      hr.prim = k_;
+      if (active) {
+        if (k_ < 0) {                          // ray_tracer.py:500-502 (0 + 1*bg == bg exactly)
+          float* dst = fb + 3 * (size_t)r.lp;
+          dst[0] = (float)sc.bg[0]; dst[1] = (float)sc.bg[1]; dst[2] = (float)sc.bg[2];
+          active = false;
+        }
+      }
+      fused_hits += (uint32_t)__popcll(__ballot(active));
+    } else if (active) {
+      hr = hits[h];
+      r = load_ray(level, hr.slot, cam, fp.rs, q);
+    }
+    if (fused && !__any(active)) {             // a tile of background pixels: nothing to shade
+      uint32_t nc_ = 0;
+      if (lane == 0) nc_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+      chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)nc_));
+      continue;
+    }
     if (active) {
-      const HitRec hr = hits[h];
-      const RayIn r = load_ray(level, hr.slot, cam, fp.rs, q);
       const Prim& op = P[hr.prim];
       const d3 n = prim_normal(op, r.o, r.d, hr.t);
       const d3 hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
@@ -1123,6 +1153,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)next_cursor));
     if (prof) ck_sync += clock64() - ck_s1;
   }
+  if (fused && lane == 0 && fused_hits != 0u) atomicAdd(&C->n_hits[0], fused_hits);
   if (prof && lane == 0) {
     atomicAdd(&C->queries, (unsigned long long)ck_sync);
     atomicAdd(&C->dbg[0], (unsigned long long)ck_hit); atomicAdd(&C->dbg[1], (unsigned long long)ck_setup);
@@ -1133,11 +1164,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
 #ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)
 // Scenes served: up to 6 spheres + 2 planes without boxes, or up to 4 spheres + 2 planes + 4 boxes,
 // any shadow grid with lights * n^2 <= LS_MAX_CELLS.  Returns false -> caller uses another kernel.
+// Does k_shade_ls serve this scene / frame?  (launch_frame asks before level 0: the kernel then traces the camera rays itself.)
+static bool shade_ls_serves(const DevScene& ds, const FrameParams& fp) {
+  const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
+  if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
+  if (ds.nB == 0) return ds.nS <= 16;
+  return ds.nB <= 4 && ds.nS <= 4;
+}
+
 static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
                             RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
                             hipStream_t st) {
-  const int side = fp.n_shadow > 1 ? fp.n_shadow : 1;
-  if (ds.nL * side * side > LS_MAX_CELLS || ds.nP > 2 || ds.nL > LS_MAX_LIGHTS || ds.nM > LS_MAX_MATS) return false;
+  if (!shade_ls_serves(ds, fp)) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
