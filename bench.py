@@ -179,6 +179,20 @@ def main():
         rendered = [torch.cuda.Event() for _ in range(2)]
         tile_free = [None, None]
     frame_no = [0]
+    gather_events = []      # (start, end) on the stream the gather runs on, for the frames whose kernels are event-timed too
+
+    def timed_gather(stream, k, *a, **kw):
+        """gather_tiles on `stream` (already current); every `every`-th frame is bracketed with events so that the N > 1
+        line can say how long the gather + reassembly took on this rank (on rank 0 that includes waiting for the
+        slowest peer's tile: compare with compute_ms to see which side bounds the frame)."""
+        if args.no_timing or k % every != 0:
+            return gather_tiles(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = gather_tiles(*a, **kw)
+        e1.record(stream)
+        gather_events.append((e0, e1))
+        return r
 
     def step(stats):
         k = frame_no[0]; frame_no[0] += 1
@@ -188,7 +202,7 @@ def main():
                       part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
             if world > 1:
                 with torch.cuda.stream(serial_stream):      # same stream as the kernels: ordered after them
-                    gather_tiles(tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+                    timed_gather(serial_stream, k, tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             return
         b = k & 1
         render_stream = render_streams[b]
@@ -199,7 +213,7 @@ def main():
         rendered[b].record(render_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[b])
-            gather_tiles(tiles[b], tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
+            timed_gather(comm_stream, k, tiles[b], tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             ev = torch.cuda.Event(); ev.record(comm_stream); tile_free[b] = ev
 
     def barrier():
@@ -217,6 +231,7 @@ def main():
     for sc_ in scenes:
         sc_.sync()
     frame_no[0] = 0
+    gather_events.clear()
     all_stats = [_lib.Stats() for _ in range(args.steps)]
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -237,6 +252,25 @@ def main():
         elapsed = float(tmax[0]); rays, hits, shadow = (float(x) for x in sums)
     else:
         rays, hits, shadow = float(last.rays), float(last.hits), float(last.shadow_rays)
+
+    # N > 1: what each rank spent computing (first kernel start -> last kernel end of its event-timed frames, rt_stats.total_ms)
+    # and in the gather (events on the stream the gather runs on), so that the first hardware run can be read from its own
+    # line: compute_ms.max ~ ms_per_step means the slowest rank's kernels bound the frame, gather_ms ~ ms_per_step the link
+    multi = None
+    if world > 1:
+        timed_mine = [s_ for k, s_ in enumerate(all_stats) if k % every == 0] if not args.no_timing else []
+        comp = sum(s_.total_ms for s_ in timed_mine) / max(len(timed_mine), 1)
+        gath = sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)
+        mine = torch.tensor([comp, gath, float(tiling.n_rows(rank))], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        per = [[float(x) for x in t] for t in every_rank]
+        multi = {"compute_ms": {"per_rank": [round(p_[0], 4) for p_ in per], "max": round(max(p_[0] for p_ in per), 4), "min": round(min(p_[0] for p_ in per), 4)},
+                 "gather_ms": {"per_rank": [round(p_[1], 4) for p_ in per], "rank0": round(per[0][1], 4)},
+                 "rows_per_rank": [int(p_[2]) for p_ in per], "tile_rows_gathered": tiling.max_rows,
+                 "frames_with_events": len(timed_mine), "pipelined": bool(pipelined),
+                 "note": "compute_ms: first kernel start -> last kernel end of a rank's frame (HIP events on its render stream); gather_ms: "
+                         "torch.distributed.gather of the padded tiles + reassembly on the stream it runs on (rank 0 waits for the slowest peer)"}
 
     verify = None
     if not args.no_verify and world > 1 and rank == 0:
@@ -341,6 +375,8 @@ def main():
             roofline["traffic"] = None      # the PMC pass (profiles/) measured full-frame launches on one GPU
         if verify is not None:
             out["verify"] = verify
+        if multi is not None:
+            out["multi"] = multi
         if world == 1:
             # The drop-in boundary: render_hip(...) as the reference's CLI would call it — scene objects in, host image out
             # (PCIe-inclusive, so never `value`).  fp32 frames come back as float32 (pinned, pooled); second call onwards.

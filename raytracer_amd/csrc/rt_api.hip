@@ -1032,7 +1032,12 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
   // RT_FUSE0=0 keeps the two-kernel level 0 (A/B).
   FrameParams fp = fp_in;
   const bool ls_kernel = fr->precision == RT_FP32 && lds && s->shade_variant == 0 && s->n_coincident == 0 && shade_ls_serves(s->ds, fp);
-  fp.fuse0 = (ls_kernel && !(getenv("RT_FUSE0") && atoi(getenv("RT_FUSE0")) == 0)) ? 1u : 0u;
+  // (fp64 frames of LDS-resident scenes: k_shade_exact_items fuses its level 0 the same way)
+  const bool items_kernel = fr->precision == RT_FP64 && lds && (fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1) <= ITEM_CHUNK &&
+                            !(getenv("RT_EXACT_ITEMS") && atoi(getenv("RT_EXACT_ITEMS")) == 0);
+  // (measured neutral there — original.txt 1080p: trace -0.035 ms, shade +0.06 ms —, so off unless RT_FUSE0_FP64=1)
+  const bool fuse_fp64 = items_kernel && getenv("RT_FUSE0_FP64") && atoi(getenv("RT_FUSE0_FP64")) == 1;
+  fp.fuse0 = ((ls_kernel || fuse_fp64) && !(getenv("RT_FUSE0") && atoi(getenv("RT_FUSE0")) == 0)) ? 1u : 0u;
   const int grid = s->num_cu * 8;
   RayQueue q[2] = {make_queue(wb, 0), make_queue(wb, 1)};
   const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
@@ -1068,7 +1073,10 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
     {
       Timed t(s, pf, 1);
       if (fr->precision == RT_FP64) {
-        if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+        // LDS-resident scenes: the shadow samples of the penumbra lanes spread over the wave (k_shade_exact_items); RT_EXACT_ITEMS=0: one lane per hit (A/B)
+        if (items_kernel)
+          hipLaunchKernelGGL((k_shade_exact_items<FB>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+        else if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
         else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel

@@ -274,16 +274,19 @@ __device__ __forceinline__ double nearest(const Prim* __restrict__ P, int nS, in
 // (oc.d)^2 - (|oc|^2 - r^2) with a margin of 1e-5 (|oc|^2 + r^2), two orders of magnitude above its fp32 rounding.  A
 // skipped sphere has an exactly negative discriminant for every lane (t = INF), which changes neither the minimum nor
 // the (t, orig) tie rule.  Must be called convergently (wave-level vote).
-__device__ __forceinline__ double nearest_coherent(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out, double plane_thr) {
+__device__ __forceinline__ double nearest_coherent(const Prim* __restrict__ P, int nS, int nP, int nB, d3 o, d3 d, int* k_out, double plane_thr,
+                                                   PrimMask mask = PrimMask::all()) {
   double best = RT_INF; int bk = -1; int borig = 0x7fffffff;
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float a32 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));                        // (directions need not be unit)
   int k = 0;
   for (int e = nS; k < e; ++k) {
+    if (!mask.has(k)) continue;
     const double ox = o.x - P[k].a[0], oy = o.y - P[k].a[1], oz = o.z - P[k].a[2];
     const float fx = (float)ox, fy = (float)oy, fz = (float)oz, r2 = (float)P[k].a[4];
     const float oc2 = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
     const float b = fmaf(fz, dz, fmaf(fy, dy, fx * dx));
-    const bool maybe = !(fmaf(b, b, r2 - oc2) < -1e-5f * (oc2 + r2));          // (NaN / inf: tested exactly)
+    const bool maybe = !(fmaf(b, b, a32 * (r2 - oc2)) < -1e-5f * a32 * (oc2 + r2));      // (NaN / inf: tested exactly)
     if (!__any(maybe)) continue;
     double t = RT_INF;
     if (maybe) t = sphere_t(P[k], o, d);
@@ -291,11 +294,13 @@ __device__ __forceinline__ double nearest_coherent(const Prim* __restrict__ P, i
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP; k < e; ++k) {
+    if (!mask.has(k)) continue;
     double t = plane_t(P[k], o, d, plane_thr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
   }
   for (int e = nS + nP + nB; k < e; ++k) {
+    if (!mask.has(k)) continue;
     double t = box_hit<false>(P[k], o, d, nullptr);
     int og = P[k].orig;
     if (t < best || (t == best && og < borig && bk >= 0)) { best = t; bk = k; borig = og; }
@@ -758,6 +763,9 @@ __device__ __forceinline__ d3 prim_normal(const Prim& p, d3 o, d3 d, double t) {
 // remaining > EPS without the 20-step cap (SEQ_WALK_CAP only guards the GPU against a runaway
 // loop) and returns exactly 0 once the product drops below EPS.
 constexpr int SEQ_WALK_CAP = 1 << 16;
+// COHERENT: the wave's rays are neighbours (the items of k_shade_exact_items: samples of a few adjacent hits towards one
+// light) over a small scene — the queries go through nearest_coherent (same results, exact sphere tests skipped per wave).
+template <bool COHERENT = false>
 __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS, int nP, int nB,
                                               const double* __restrict__ mats, d3 o, d3 d, double maxdist,
                                               int* queries, bool seq = false, double plane_thr = HIT_EPS,
@@ -766,7 +774,7 @@ __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS
   const int cap = seq ? SEQ_WALK_CAP : WALK_CAP;
   for (int step = 0; step < cap; ++step) {
     if (seq && !(remaining > EPS)) break;                        // :303
-    int k; double t = nearest(P, nS, nP, nB, o, d, &k, plane_thr, ac, mask);
+    int k; double t = COHERENT ? nearest_coherent(P, nS, nP, nB, o, d, &k, plane_thr, mask) : nearest(P, nS, nP, nB, o, d, &k, plane_thr, ac, mask);
     ++*queries;
     if (!((t < remaining) && k >= 0)) break;                     // :269-272, :290-291
     trans *= mats[MAT_STRIDE * P[k].mat + 10];                   // :276-279

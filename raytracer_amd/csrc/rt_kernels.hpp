@@ -770,6 +770,40 @@ __device__ __attribute__((noinline)) uint32_t exact_retest(const double* __restr
 
 struct ExactHit { d3 hp, n; const double* mat; double c[3]; };   // shading result of one hit
 
+// One light's Phong terms for one hit, given the light's shadow term T: ray_tracer.py:530-557, literal fp64
+// (seq: the sequential renderer's grouping and rules, :343-359).
+__device__ __forceinline__ void phong_light_exact(const double* __restrict__ lg, const double* __restrict__ mat, d3 hp, d3 n, d3 v, double T,
+                                                  bool seq, double (&dif)[3], double (&spc)[3]) {
+  const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+  double I = (1 - lg[7]) + lg[7] * T;                                            // :543
+  if (seq && I < EPS) return;                                                    // sequential: :347-348
+  d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
+  double ldist = norm3(tl);
+  d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+  d3 ml = mk3(-l.x, -l.y, -l.z);
+  double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
+  if (seq) {                                                                     // :351 ((Kd*Lc)*I)*ndl
+    dif[0] += ((mat[0] * lg[3]) * I) * ndl; dif[1] += ((mat[1] * lg[4]) * I) * ndl; dif[2] += ((mat[2] * lg[5]) * I) * ndl;
+  } else {
+    double s1 = I * ndl;
+    dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
+  }
+  double dn = dot3(ml, n);                                                       // :549
+  d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
+  double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
+  if (seq) {                                                                     // :356-359, only when r.v > 0
+    if (rdv > 0) {
+      const double pw = pow(rdv, mat[9]);
+      spc[0] += (((mat[3] * lg[3]) * lg[6]) * I) * pw; spc[1] += (((mat[4] * lg[4]) * lg[6]) * I) * pw;
+      spc[2] += (((mat[5] * lg[5]) * lg[6]) * I) * pw;
+    }
+  } else {
+    double s2 = I * pow(rdv, mat[9]);                                            // :555-556
+    spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
+    spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
+  }
+}
+
 // Literal fp64 restatement of ray_tracer.py:517-563 for one hit, with compute_soft_shadow_batch
 // (:171-244) and compute_shadow_transmission_batch (:247-293) inlined.  c = (diffuse+specular)*(1-transparency).
 template <typename JIT>
@@ -788,36 +822,8 @@ __device__ __forceinline__ ExactHit shade_hit_exact(const DevScene& sc, const Pr
   const d3 p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);          // :538
   double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
   for (int li = 0; li < sc.nL; ++li) {                                             // :526
-    const double* lg = sc.lights + LIGHT_STRIDE * li;
-    const d3 Lp = mk3(lg[0], lg[1], lg[2]);
     const double T = soft_shadow_exact(sc, P, p, li, n_sh, jit, queries, seq, pthr, ac);
-    double I = (1 - lg[7]) + lg[7] * T;                                            // :543
-    if (seq && I < EPS) continue;                                                  // sequential: :347-348
-    d3 tl = mk3(Lp.x - hp.x, Lp.y - hp.y, Lp.z - hp.z);                            // :530-532 (un-offset hp)
-    double ldist = norm3(tl);
-    d3 l = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
-    d3 ml = mk3(-l.x, -l.y, -l.z);
-    double ndl = dot3(n, l); if (!(ndl > 0)) ndl = 0;                              // :545
-    if (seq) {                                                                     // :351 ((Kd*Lc)*I)*ndl
-      dif[0] += ((mat[0] * lg[3]) * I) * ndl; dif[1] += ((mat[1] * lg[4]) * I) * ndl; dif[2] += ((mat[2] * lg[5]) * I) * ndl;
-    } else {
-      double s1 = I * ndl;
-      dif[0] += (mat[0] * lg[3]) * s1; dif[1] += (mat[1] * lg[4]) * s1; dif[2] += (mat[2] * lg[5]) * s1;   // :547
-    }
-    double dn = dot3(ml, n);                                                       // :549
-    d3 rf = mk3(ml.x - (2 * dn) * n.x, ml.y - (2 * dn) * n.y, ml.z - (2 * dn) * n.z);
-    double rdv = dot3(rf, v); if (!(rdv > 0)) rdv = 0;                             // :550
-    if (seq) {                                                                     // :356-359, only when r.v > 0
-      if (rdv > 0) {
-        const double pw = pow(rdv, mat[9]);
-        spc[0] += (((mat[3] * lg[3]) * lg[6]) * I) * pw; spc[1] += (((mat[4] * lg[4]) * lg[6]) * I) * pw;
-        spc[2] += (((mat[5] * lg[5]) * lg[6]) * I) * pw;
-      }
-    } else {
-      double s2 = I * pow(rdv, mat[9]);                                            // :555-556
-      spc[0] += ((mat[3] * lg[3]) * lg[6]) * s2; spc[1] += ((mat[4] * lg[4]) * lg[6]) * s2;
-      spc[2] += ((mat[5] * lg[5]) * lg[6]) * s2;
-    }
+    phong_light_exact(sc.lights + LIGHT_STRIDE * li, mat, hp, n, v, T, seq, dif, spc);
   }
   const double one_m = 1 - mat[10];                                                // :562
   out.hp = hp; out.n = n; out.mat = mat;
@@ -860,6 +866,176 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
   }
+}
+
+// fp64 shading of a hit queue for LDS-resident scenes, shadow samples spread over the lanes (round 3).
+// k_shade_exact gives a hit to a lane, and the lane walks its lights x n x n shadow samples one after the other; after
+// fan_cull only the penumbra lanes of a wave are still in those loops (a quarter of them on original.txt), the others
+// wait.  Here the samples of the penumbra lanes become ITEMS: per light, the lanes that need sampling are listed
+// (ballot + mbcnt), each computes the light's basis for its hit once (ray_tracer.py:198-213) and parks it in LDS, and then
+// the wave works through (listed hit, cell) items 64 at a time, so the walks run on full waves; the terms are parked in
+// LDS and each listed hit's lane adds its own n^2 terms left to right.  Per sample AND per sum the arithmetic and its
+// order are those of soft_shadow_exact: results are bit-identical to k_shade_exact's.
+constexpr int ITEM_CHUNK = 512;
+template <typename FB>
+__global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+                                                             RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
+                                                             FB* __restrict__ fb) {
+  __shared__ Prim s_prims[LDS_PRIMS];
+  __shared__ double s_p[3][BLOCK];              // shadow origin of each lane's hit
+  __shared__ double s_basis[BLOCK / 64][64][6]; // per wave: (right, up) of the listed hits for the current light
+  __shared__ double s_T[BLOCK / 64][64];        // per wave: shadow term of the listed hits
+  __shared__ double s_cellT[BLOCK / 64][ITEM_CHUNK];   // per wave: the terms of a chunk of items
+  __shared__ uint32_t s_gpix[BLOCK];
+  __shared__ unsigned char s_list[BLOCK / 64][64];
+  const Prim* P = stage_scene<true>(sc, s_prims);
+  // level 0 fused with the nearest-hit query (fp.fuse0), as in k_shade_ls: slots are pixels, every lane traces its own
+  // camera ray (nearest_coherent: the literal fp64 tests, skipped per wave for spheres no lane can hit)
+  const bool fused = level == 0 && fp.fuse0 != 0u;
+  uint32_t count = fused ? C->n_rays[0] : C->n_hits[level];
+  if (count > fp.hit_cap) count = fp.hit_cap;
+  uint32_t fused_hits = 0u;
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, t_ = threadIdx.x;
+  const int n_sh = fp.n_shadow;
+  const int n_cells = n_sh > 1 ? n_sh * n_sh : 1;
+  const int hits_per_chunk = max(1, ITEM_CHUNK / n_cells);       // (launch_frame uses this kernel for n^2 <= ITEM_CHUNK only)
+  const bool seq = fp.sequential != 0;
+  unsigned long long my_queries = 0ull;
+  for (;;) {
+    const uint32_t base = grab64(&C->work_shade[level]);
+    if (base >= count) break;
+    const uint32_t h = base + lane;
+    bool active = h < count;
+    RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0), v = mk3(0, 0, 0), p = mk3(0, 0, 0);
+    const double* mat = sc.mats;
+    r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
+    HitRec hr;
+    if (fused) {
+      r = load_ray(0, active ? h : count - 1, cam, fp.rs, q);
+      int k_ = -1;
+      hr.t = nearest_coherent(P, sc.nS, sc.nP, sc.nB, r.o, r.d, &k_, fp.plane_thr);
+      hr.prim = k_; hr.slot = h;
+      if (active && k_ < 0) {                  // ray_tracer.py:500-502 (0 + 1*bg == bg exactly)
+        fb[3 * (size_t)r.lp + 0] = (FB)sc.bg[0]; fb[3 * (size_t)r.lp + 1] = (FB)sc.bg[1]; fb[3 * (size_t)r.lp + 2] = (FB)sc.bg[2];
+      }
+      active = active && k_ >= 0;
+      const unsigned long long mh = __ballot(active);
+      fused_hits += (uint32_t)__popcll(mh);
+      if (mh == 0ull) continue;                // a tile of background pixels
+      if (k_ < 0) {                            // a lane without a hit of its own shades a copy of a neighbour's (results dropped)
+        const int srcl = __ffsll((long long)mh) - 1;
+        hr.prim = __shfl(hr.prim, srcl); hr.t = __shfl(hr.t, srcl);
+        r.d = mk3(__shfl(r.d.x, srcl), __shfl(r.d.y, srcl), __shfl(r.d.z, srcl));
+      }
+    } else {
+      // (the idle lanes of a level's last wave shade a copy of its last hit, results dropped: fan_cull votes per wave)
+      hr = hits[active ? h : count - 1];
+      r = load_ray(level, hr.slot, cam, fp.rs, q);
+    }
+    {
+      const Prim& pr = P[hr.prim];
+      n = prim_normal(pr, r.o, r.d, hr.t);
+      hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);      // :517
+      mat = sc.mats + MAT_STRIDE * pr.mat;
+      v = mk3(r.o.x - hp.x, r.o.y - hp.y, r.o.z - hp.z);                                // :519
+      double vn = norm3(v); if (vn < EPS) vn = seq ? 1.0 : EPS;
+      v = mk3(v.x / vn, v.y / vn, v.z / vn);
+      p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);                    // :538
+    }
+    s_p[0][t_] = p.x; s_p[1][t_] = p.y; s_p[2][t_] = p.z;
+    s_gpix[t_] = global_pixel(fp.rs, r.lp);
+    double dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+    for (int li = 0; li < sc.nL; ++li) {                                                // :526
+      const double* lg = sc.lights + LIGHT_STRIDE * li;
+      const d3 Lp = mk3(lg[0], lg[1], lg[2]);
+      const FanCull fc = fan_cull(sc, P, p, Lp, n_sh > 1 ? 0.7072f * (float)lg[8] : 0.0f);
+      const bool need = active & fc.lane_can & !fc.lane_full;    // (the copies in the idle lanes of a last wave are not listed)
+      double T = fc.lane_full ? 0.0 : 1.0;                       // the conservative claims: n^2 terms of exactly 0 / 1
+      if (active && !need) my_queries += (unsigned long long)n_cells;                   // (one query per walk, as the walks would count)
+      const unsigned long long m = __ballot(need);
+      const int n_need = __popcll(m);
+      if (n_need > 0) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (need) {
+          s_list[wave][rank] = (unsigned char)lane;
+          if (n_sh > 1) {                                        // the light's basis for this hit, once (:198-213)
+            const d3 tl = mk3(Lp.x - p.x, Lp.y - p.y, Lp.z - p.z);
+            const double ldist = norm3(tl);
+            const d3 ld = mk3(tl.x / ldist, tl.y / ldist, tl.z / ldist);
+            const d3 ref = (fabs(ld.x) >= 0.9) ? mk3(0, 1, 0) : mk3(1, 0, 0);
+            d3 right = cross3(ld, ref);
+            double rn = norm3(right); if (rn < EPS) rn = EPS;
+            right = mk3(right.x / rn, right.y / rn, right.z / rn);
+            d3 up = cross3(right, ld);
+            double un = norm3(up); if (un < EPS) un = EPS;
+            up = mk3(up.x / un, up.y / un, up.z / un);
+            double* b = s_basis[wave][rank];
+            b[0] = right.x; b[1] = right.y; b[2] = right.z; b[3] = up.x; b[4] = up.y; b[5] = up.z;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double radius = lg[8], cw = radius / (n_sh > 1 ? n_sh : 1);                // :215
+        // items = (listed hit, cell), dense: item i is cell i % n^2 of listed hit i / n^2, 64 items per round, so a light
+        // never takes more rounds than the n^2 sample iterations of the one-lane-per-hit kernel.  The terms go to LDS in
+        // chunks of <= ITEM_CHUNK items (whole hits) and each listed hit's lane adds its n^2 terms left to right, the
+        // reference's own order (ray_tracer.py:241).
+        for (int e0 = 0; e0 < n_need; e0 += hits_per_chunk) {
+          const int n_e = min(hits_per_chunk, n_need - e0), n_items = n_e * n_cells;
+          for (int i0 = 0; i0 < n_items; i0 += 64) {
+            const int it = i0 + (int)lane;
+            if (it < n_items) {
+              const int el = it / n_cells, cell = it - el * n_cells, e = e0 + el;
+              const uint32_t src = wave * 64u + s_list[wave][e];
+              const d3 pe = mk3(s_p[0][src], s_p[1][src], s_p[2][src]);
+              d3 sp = Lp;
+              if (n_sh > 1) {
+                const double* b = s_basis[wave][e];
+                const JitKey key = jit_light_key(fp.seed, s_gpix[src], (uint32_t)level, (uint32_t)li);
+                const int i = cell / n_sh, j = cell - i * n_sh;
+                const double oi = -radius / 2 + cw * (i + (double)jit_ui(key, (uint32_t)cell));    // :224-225
+                const double oj = -radius / 2 + cw * (j + (double)jit_uj(key, (uint32_t)cell));
+                sp = mk3((Lp.x + oi * b[0]) + oj * b[3], (Lp.y + oi * b[1]) + oj * b[4], (Lp.z + oi * b[2]) + oj * b[5]);
+              }
+              const d3 ts = mk3(sp.x - pe.x, sp.y - pe.y, sp.z - pe.z);
+              const double dist = norm3(ts);
+              const d3 dir = mk3(ts.x / dist, ts.y / dist, ts.z / dist);
+              const d3 so = mk3(pe.x + dir.x * EPS, pe.y + dir.y * EPS, pe.z + dir.z * EPS);
+              int qn = 0;
+              s_cellT[wave][it] = shadow_walk<true>(P, sc.nS, sc.nP, sc.nB, sc.mats, so, dir, dist - EPS, &qn, seq, fp.plane_thr, nullptr, fc.act);
+              my_queries += (unsigned long long)qn;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if ((int)lane < n_e) {
+            double total = 0.0;
+            for (int c = 0; c < n_cells; ++c) total += s_cellT[wave][(int)lane * n_cells + c];
+            s_T[wave][e0 + (int)lane] = total / (double)n_cells;                        // :243
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (need) T = s_T[wave][rank];
+      }
+      phong_light_exact(lg, mat, hp, n, v, T, seq, dif, spc);
+    }
+    if (active) {
+      const double one_m = 1 - mat[10];                                                  // :562
+      double c0 = (dif[0] + spc[0]) * one_m, c1 = (dif[1] + spc[1]) * one_m, c2 = (dif[2] + spc[2]) * one_m;
+      if (seq_background_term(fp, level, mat)) {                                         // :370-377
+        c0 += sc.bg[0] * mat[10]; c1 += sc.bg[1] * mat[10]; c2 += sc.bg[2] * mat[10];
+      }
+      fb_put(fb, level == 0, r.lp, r.w.x * c0, r.w.y * c1, r.w.z * c2);                  // :563
+    }
+    spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
+  }
+  for (int o_ = 32; o_ > 0; o_ >>= 1) my_queries += __shfl_xor(my_queries, o_);
+  if (lane == 0 && my_queries) atomicAdd(&C->queries, my_queries);
+  if (fused && lane == 0 && fused_hits) atomicAdd(&C->n_hits[0], fused_hits);
 }
 
 // --------------------------------------------------------------------------- k_fix_exact -------

@@ -167,3 +167,8 @@ def test_bench_two_ranks_on_one_device(pipeline):
     assert out["verify"]["ranks"] == 2
     assert out["verify"]["max_abs_diff_vs_single_gpu_frame"] == 0.0
     assert out["config"]["radiance_rays"] == 381520        # both ranks' rays add up to the frame's
+    # the keys a first hardware run is read from: per-rank compute vs gather time
+    m = out["multi"]
+    assert len(m["compute_ms"]["per_rank"]) == 2 and len(m["gather_ms"]["per_rank"]) == 2 and m["frames_with_events"] >= 1
+    assert m["compute_ms"]["max"] >= m["compute_ms"]["min"] > 0.0 and m["gather_ms"]["rank0"] > 0.0
+    assert sum(m["rows_per_rank"]) == 500 and m["pipelined"] == (pipeline == "1")

@@ -87,3 +87,48 @@ def test_small_queues_blocking_retry_and_async_report(oracle, monkeypatch):
             assert gs.last_stats["rays"] == ostats["rays"] and max(gs.last_stats["level_rays"]) > 1.5 * W * H
     finally:
         hip.hipFree(buf)
+
+
+def test_level0_fusion_switches_change_nothing(monkeypatch):
+    """Level 0 fused with the nearest-hit query (k_shade_ls: default; k_shade_exact_items: RT_FUSE0_FP64=1) against the
+    two-kernel level 0 (RT_FUSE0=0): same rays, same hits, same pixels — a frame with background tiles, partial tiles
+    and a ragged right / bottom edge."""
+    import numpy as np
+    from conftest import scene_path
+    from raytracer_amd import load_scene
+    from raytracer_amd.render import GpuScene
+    from raytracer_amd import parse_scene_text, separate_objects
+    text = """cam 0 1 7  0 0.5 0  0 1 0  1.2 2.4
+set 0.1 0.2 0.4 3 3
+mtl 0.7 0.3 0.2 0.6 0.6 0.6 0.3 0.3 0.3 20 0.0
+mtl 0.2 0.6 0.8 0.9 0.9 0.9 0.1 0.1 0.1 50 0.5
+mtl 0.6 0.6 0.6 0.3 0.3 0.3 0.2 0.2 0.2 5 0.0
+sph -1.2 0.5 0 1.0 1
+sph 1.0 0.8 0.5 0.8 2
+sph 0.2 -0.4 1.5 0.4 3
+box 2.5 0.0 -1.0 1.0 3
+lgt 3 5 4 0.9 0.9 0.8 1 0.8 1.0
+lgt -4 3 2 0.4 0.5 0.7 1 0.6 0.5
+"""
+    cam, st, objs = parse_scene_text(text)
+    mats, surfs, lights = separate_objects(objs)
+    W, H = 203, 77
+    cam.setup(W / H)
+    with GpuScene.from_objects(mats, surfs, lights, st.background_color) as gs:
+        out = {}
+        for name, env in (("fused", {}), ("split", {"RT_FUSE0": "0"}), ("fused64", {"RT_FUSE0_FP64": "1"})):
+            for k in ("RT_FUSE0", "RT_FUSE0_FP64"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v_ in env.items():
+                monkeypatch.setenv(k, v_)
+            a32 = gs.render(cam, W, H, 3, 3, precision="fp32", jitter=21).copy(); s32 = dict(gs.last_stats)
+            a64 = gs.render(cam, W, H, 3, 3, precision="fp64", jitter=21).copy(); s64 = dict(gs.last_stats)
+            out[name] = (a32, s32, a64, s64)
+        for name in ("split", "fused64"):
+            for k in ("rays", "hits", "shadow_rays", "level_rays", "level_hits"):
+                assert out[name][1][k] == out["fused"][1][k], (name, k)
+                assert out[name][3][k] == out["fused"][3][k], (name, k)
+            assert out[name][3]["segments"] == out["fused"][3]["segments"]
+            assert np.abs(out[name][0] - out["fused"][0]).max() < 2e-6          # (order of a pixel's atomic adds at levels >= 1)
+            assert np.abs(out[name][2] - out["fused"][2]).max() < 1e-13
+        assert out["fused"][1]["level_hits"][0] < W * H                        # the frame has background pixels
