@@ -635,7 +635,11 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   bool any_transparent = false;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) any_transparent = true;
   int n_coincident = any_transparent ? mark_coincident(prims) : 0;
-  if (any_transparent && !(getenv("RT_NEAR_PAIRS") && atoi(getenv("RT_NEAR_PAIRS")) == 0)) n_coincident += mark_near_pairs(prims, mats);
+  if (any_transparent && !(getenv("RT_NEAR_PAIRS") && atoi(getenv("RT_NEAR_PAIRS")) == 0)) {
+    const int n_near = mark_near_pairs(prims, mats);
+    if (getenv("RT_DEBUG_STATS")) fprintf(stderr, "[rt debug] scene of %zu primitives: %d marked as coincident, %d as meeting another surface\n", prims.size(), n_coincident, n_near);
+    n_coincident += n_near;
+  }
 
   rt_scene* s = new (std::nothrow) rt_scene();
   if (!s) return fail(RT_ERR_NOMEM, "out of host memory");

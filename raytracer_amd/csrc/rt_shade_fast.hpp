@@ -68,13 +68,17 @@ __device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, 
     const float b = fmaf((float)ocz, dz, fmaf((float)ocy, dy, (float)ocx * dx));
     const float disc = fmaf(b, b, -cc);
     const float bound = fmaf(kap, fabsf(b), kap0);
-    if (disc > bound) {                                   // (grazing samples are deferred to fp64 by the sample block: not here)
+    if (disc > bound) {
       const float sq = raw_sqrt(disc);
       const float t1 = b < 0.0f ? sq - b : -b - sq;       // the root that does not cancel
       const float e1 = e_b + bound * raw_rcp(sq) + 4.0f * U1 * fabsf(t1);
       const float t2 = cc * raw_rcp(t1);
       r.t0 = t1; r.e0 = e1;
       r.t1 = t2; r.e1 = fabsf(t2) * (e1 * raw_rcp(fabsf(t1)) + 4.0f * U1);
+    } else if (disc >= -bound) {
+      // a grazing sample (its own hit / miss decision is made in fp64 by the sample block): if the sphere is crossed at
+      // all, both crossings lie within sqrt(|disc| + bound) of the point of closest approach
+      r.t0 = -b; r.e0 = e_b + raw_sqrt(2.0f * bound) + 4.0f * U1 * fabsf(b);
     }
   } else if (s_.type == 1) {
     const float num = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
@@ -82,7 +86,7 @@ __device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, 
     if (fabsf(den) > 2.0f * U8) {
       const float t = num * raw_rcp(den);
       r.t0 = t; r.e0 = fabsf(t) * (1.5f * U8 * raw_rcp(fabsf(den)) + 4.0f * U1);
-    }
+    } else { r.t0 = 1.0f; r.e0 = 3.0e38f; }               // parallel within rounding: nothing is known about the root
   } else {
     const float jx = raw_rcp(dx), jy = raw_rcp(dy), jz = raw_rcp(dz);
     const float ax = (float)(s_.a[0] - p.x) * jx, bx = (float)(s_.a[3] - p.x) * jx;
@@ -92,7 +96,8 @@ __device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, 
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
     const float rel = 2.0f * fmaf(U8, jm, 4.0f * U1);
-    if (tn <= tf + rel * (fabsf(tn) + fabsf(tf)) && jm <= 1e3f) {
+    if (jm > 1e3f) { r.t0 = 1.0f; r.e0 = 3.0e38f; }        // a component nearly parallel to a slab: nothing is known about the roots -> "close to everything"
+    else if (tn <= tf + rel * (fabsf(tn) + fabsf(tf))) {
       r.t0 = tn; r.e0 = rel * fabsf(tn);
       r.t1 = tf; r.e1 = rel * fabsf(tf);
     }
@@ -323,8 +328,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
           // sample of this chunk crosses; two of them in one sample may be closer than 2e-6 -> compared after the chunk's primitives
           int pk0 = -1, pk1 = -1, pk2 = -1, pk3 = -1, npk = 0;
           auto note_marked = [&](int k_, bool crossed, bool deferred) __attribute__((always_inline)) {
-            if (deferred) unc = 1.0f;              // a decision of a marked primitive left to fp64: the walk sorts it out
-            else if (crossed) {
+            // (a sample whose decision is left to fp64 may cross too: pair_roots gives such samples a wide error bound)
+            if (crossed | deferred) {
               if (npk == 0) pk0 = k_; else if (npk == 1) pk1 = k_; else if (npk == 2) pk2 = k_; else if (npk == 3) pk3 = k_; else unc = 1.0f;
               ++npk;
             }

@@ -70,4 +70,4 @@ lgt -4 6 2 0.5 0.6 0.9 1 0.7 1.0
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 7), precision="fp32", stats=s32, verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"n_shadow {n_sh}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
-        assert 0 < s32["retested"] < s32["hits"] * len(lights)          # the exact walk is the exception, not the rule
+        assert s32["retested"] < 0.25 * s32["hits"] * len(lights)       # the exact walk is the exception, not the rule
