@@ -699,6 +699,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             if (dm0 == 0u) { dk0 = dk1; dm0 = dm1; dk1 = -1; dm1 = 0u; }
           }
           if (!OPAQUE && ncross > WALK_CAP && !fp.sequential) unc = 1.0f;   // a sample may cross more surfaces than the walk visits
+#pragma unroll
+          for (int s = 0; s < CH; ++s) total += tr[s];
+          // (after the sum: the chunk's per-sample register arrays are dead here, the check below has the registers to itself)
           if (!OPAQUE && __any((npk >= 2) & (npk <= 4) & !(unc >= 0.0f))) {
             // merged crossings (see pair_roots): per sample, the roots of every two marked primitives the chunk crosses.
             // Rare (segments through the neighbourhood of an intersection curve), so the sample's direction is formed
@@ -729,8 +732,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (close) unc = 1.0f;
             }
           }
-#pragma unroll
-          for (int s = 0; s < CH; ++s) total += tr[s];
         }
         if ((RT_DBG(fp) & 2u) && LDS_SCENE && active) {      // audit build, shortcut disabled: check what it would have claimed
           if (lane_lit && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
