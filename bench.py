@@ -118,7 +118,7 @@ def main():
     import torch.distributed as dist
     from raytracer_amd import _lib
     from raytracer_amd.dist import RowTiling, cache_row_indices, gather_tiles, new_scratch
-    from raytracer_amd.flops import shade_kernel_flops, flops_per_query
+    from raytracer_amd.flops import shade_kernel_flops, flops_per_query, rays_traced_by_shade_kernel
     from raytracer_amd.packing import pack_scene
     from raytracer_amd.render import GpuScene
 
@@ -291,8 +291,10 @@ def main():
         trace_ms = sum(s.trace_ms for s in timed) / max(len(timed), 1)
         launches = max(all_stats[0].shade_launches, 1)
         seg = max(int(last.segments), 0)
+        # (frames whose shade kernel traces its own rays — k_shade_ls, fused — execute those queries in the timed launches too)
+        fused_rays, fused_children = rays_traced_by_shade_kernel(timed[0].as_dict()) if timed else (0, 0)
         flops_frame = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
-                                         hits=int(last.hits), segments=seg)
+                                         hits=int(last.hits), segments=seg, rays=fused_rays, children=fused_children)
         roofline = None
         if shade_ms > 0:
             peak = PEAK_TFLOPS[precision]
@@ -355,6 +357,7 @@ def main():
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac, "frac_basis": basis,
                         "traffic": traffic, "brute_force": brute, "culled": culled, "executed": executed,
                         "flops_per_launch": flops_frame / launches, "frames_with_events": len(timed),
+                        "rays_traced_in_shade_kernel": fused_rays,
                         "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
             if frac is not None and precision == "fp32":
                 assert frac <= 1.0, f"roofline.frac {frac} > 1: the brute-force run did not execute the model's work"

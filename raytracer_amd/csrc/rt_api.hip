@@ -1042,6 +1042,11 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
   // (measured neutral there — original.txt 1080p: trace -0.035 ms, shade +0.06 ms —, so off unless RT_FUSE0_FP64=1)
   const bool fuse_fp64 = items_kernel && getenv("RT_FUSE0_FP64") && atoi(getenv("RT_FUSE0_FP64")) == 1;
   fp.fuse0 = ((ls_kernel || fuse_fp64) && !(getenv("RT_FUSE0") && atoi(getenv("RT_FUSE0")) == 0)) ? 1u : 0u;
+  // ... and EVERY level (fuse0 = 2): k_shade_ls also traces the children of its hits and hands the next level their hits
+  // with the rays (HitRay queues in the ray-queue buffers): a frame is max_depth + 1 shade launches + k_fix_exact, no
+  // k_trace.  Needs the pixel index in 25 bits; RT_FUSE_ALL=0 keeps k_trace for the bounce levels (A/B).
+  if (ls_kernel && fp.fuse0 == 1u && (size_t)fp.rs.rows * (size_t)fp.rs.W <= (size_t)HITRAY_MAX_PIXELS &&
+      !(getenv("RT_FUSE_ALL") && atoi(getenv("RT_FUSE_ALL")) == 0)) fp.fuse0 = 2u;
   const int grid = s->num_cu * 8;
   RayQueue q[2] = {make_queue(wb, 0), make_queue(wb, 1)};
   const uint32_t P = (uint32_t)fp.rs.rows * (uint32_t)fp.rs.W;
@@ -1056,7 +1061,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
     }
     if (tgrid < 1) tgrid = 1;
     if (sgrid < 1) sgrid = 1;
-    if (!(level == 0 && fp.fuse0)) {
+    if (!(level == 0 && fp.fuse0) && fp.fuse0 != 2u) {
       Timed t(s, pf, 0);
       if (lds) hipLaunchKernelGGL((k_trace<FB, true>), dim3(tgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, wb.hits, wb.counters, fb);
       else if (level >= 1 && s->pool_trace) hipLaunchKernelGGL((k_trace_pool<FB>), dim3(s->num_cu * 4), dim3(BLOCK), 0, s->stream, s->ds, fp, level, cur, wb.hits, wb.counters, fb);

@@ -57,7 +57,25 @@ struct Counters {
   uint32_t seg_need;            // largest segment fill any level reached (unclamped: what an overflowed frame needs)
   uint32_t stripes_done;        // k_shade_ls: bit s = stripe s has no chunk left
   uint32_t stripes[32 * 32];    // k_shade_ls: chunk cursors of the NSTRIPE stripes of a level's hit list (stripe * 32)
+  // Frames in which k_shade_ls traces its own rays at every level (FrameParams::fuse0 == 2, no k_trace launch): level L
+  // reads the hit-ray queue whose segment counters are segcnt3[L % 3], appends the hits of its children to the queue of
+  // segcnt3[(L + 1) % 3] and clears segcnt3[(L + 2) % 3] (last read by level L - 1) for level L + 1 to append to;
+  // likewise the chunk cursors: level L works through stripes3[L % 3] and clears stripes3[(L + 1) % 3].
+  uint32_t segcnt3[3][64 * 32];
+  uint32_t stripes3[3][32 * 32];
 };
+
+// One hit of a bounce ray together with the ray it belongs to, 64 bytes = one cache line per lane: what k_shade_ls's
+// inline trace appends for the next level in fused frames (instead of a 76-byte SoA ray + a 16-byte HitRec that k_trace
+// reads and writes in between).  The hit point is o + t*d as every kernel forms it; the origin is not needed again.
+struct __attribute__((aligned(64))) HitRay {
+  double hp[3];    // hit point
+  double d[3];     // ray direction
+  float w[3];      // weight of the ray's radiance in its pixel (fp32 mode)
+  uint32_t pk;     // framebuffer index (25 bits) | record index << 25 (5 bits; scenes with boxes: 4 bits) | box face << 29
+};
+static_assert(sizeof(HitRay) == 64, "HitRay must be one 64-byte line");
+constexpr uint32_t HITRAY_PIX_BITS = 25, HITRAY_MAX_PIXELS = 1u << HITRAY_PIX_BITS;
 constexpr int FIX_QUEUES = 64;
 constexpr int NSEG = 64;
 static_assert(NSEG == 64, "k_trace scans the segment counters with one wave, one lane per segment");
@@ -99,7 +117,8 @@ struct FrameParams {
   double plane_thr;      // plane hit threshold: HIT_EPS, or its predecessor in sequential mode
   uint32_t fix_cap;      // capacity of ONE re-test sub-queue (FixRec); sub-queue q starts at fix[q * fix_cap]
   uint32_t brute;        // RT_FLAG_BRUTE_FORCE: fp32 kernels test every surface for every shadow sample (no culling, no shortcuts)
-  uint32_t fuse0;        // level 0 of k_shade_ls traces its own camera rays (no k_trace launch, no hit list): set per launch by launch_frame
+  uint32_t fuse0;        // 1: level 0 of the shade kernel traces its own camera rays (no k_trace launch, no hit list at level 0);
+                         // 2 (k_shade_ls): every level does, and traces its children too (HitRay queues, no k_trace at all); set by launch_frame
 };
 
 __device__ __forceinline__ uint32_t global_pixel(const RowSet& rs, uint32_t lp) {

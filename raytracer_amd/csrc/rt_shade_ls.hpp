@@ -464,6 +464,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // exact fp64 geometry of each lane's hit, parked for the spawn step and the re-test queue (hit point, normal, ray
   // direction, weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
   __shared__ double s_geo[12][BLOCK];
+  __shared__ double s_ct[2][BLOCK];            // fall: t of each lane's transmitted / reflected child that hit something
+  __shared__ uint32_t s_ck[2][BLOCK];          //       its record | box face << 8
   const int n_sh = fp.n_shadow;
   const int n_side = n_sh > 1 ? n_sh : 1;
   const int n_cells = n_side * n_side;
@@ -473,7 +475,37 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // nearest() over the staged records and shades its own hit.  No k_trace launch, no 16-byte HitRec per pixel written and
   // read back, no global load at the start of a chunk; pixels that miss get the background here.
   const bool fused = level == 0 && fp.fuse0 != 0u;
-  if (!fused && C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
+  // fp.fuse0 == 2: the frame has no k_trace launch at all.  The children of a chunk's hits are traced by the lanes that
+  // spawn them (right after the hit's geometry is known, before the light loop), misses add their background term, and
+  // the HITS are appended — ray and hit in one 64-byte HitRay — to the next level's queue, which the next launch of this
+  // kernel reads instead of HitRec + ray queue.  ray_tracer.py:491-595 as one kernel per level.
+  const bool fall = fp.fuse0 == 2u;
+  const HitRay* __restrict__ hin = reinterpret_cast<const HitRay*>(q.ox);
+  HitRay* __restrict__ hout = reinterpret_cast<HitRay*>(nq.ox);
+  uint32_t* const stripes = fall ? C->stripes3[level % 3] : C->stripes;
+  __shared__ uint32_t s_segfirst[NSEG + 1], s_segn[NSEG];      // fall, level >= 1: first chunk id / hits of each queue segment
+  const uint32_t seg_cap = fp.queue_cap / NSEG;
+  if (!fused && !fall && C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
+  if (fall) {
+    if (level >= 1 && threadIdx.x < 64) {          // lane q: segment q; inclusive scans over the wave (as in k_trace)
+      const uint32_t raw = C->segcnt3[level % 3][threadIdx.x * 32];
+      const uint32_t nq_ = min(raw, seg_cap);
+      uint32_t ch = (nq_ + 63u) / 64u, tot = nq_, worst = raw;
+#pragma unroll
+      for (int o_ = 1; o_ < 64; o_ <<= 1) {
+        const uint32_t a = __shfl_up(ch, o_), b = __shfl_up(tot, o_);
+        if ((int)threadIdx.x >= o_) { ch += a; tot += b; }
+        worst = max(worst, (uint32_t)__shfl_xor((int)worst, o_));
+      }
+      s_segfirst[threadIdx.x + 1] = ch; s_segn[threadIdx.x] = nq_;
+      if (threadIdx.x == 0) s_segfirst[0] = 0;
+      if (blockIdx.x == 0 && threadIdx.x == 63) { C->n_hits[level] = tot; atomicMax(&C->seg_need, worst); }
+    }
+    if (blockIdx.x == 0) {
+      for (int i = threadIdx.x; i < NSEG; i += BLOCK) C->segcnt3[(level + 2) % 3][i * 32] = 0u;
+      for (int i = threadIdx.x; i < NSTRIPE; i += BLOCK) C->stripes3[(level + 1) % 3][i * 32] = 0u;
+    }
+  }
   {
     const int words = sc.n * (int)(sizeof(Prim) / 16);
     const uint4* src = reinterpret_cast<const uint4*>(sc.prims);
@@ -551,9 +583,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   const int nS = sc.nS, nP = sc.nP, nB = sc.nB;
   float umbra_t0_max = 3.0e38f;                              // 1000 * (smallest sphere radius)^2
   for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
-  uint32_t count = fused ? C->n_rays[0] : C->n_hits[level];
-  if (count > fp.hit_cap) count = fp.hit_cap;
+  const bool qin = fall && level >= 1;                       // this level's hits come from the HitRay queue
+  uint32_t count = fused ? C->n_rays[0] : (qin ? s_segfirst[NSEG] * 64u : C->n_hits[level]);
+  if (!qin && count > fp.hit_cap) count = fp.hit_cap;
   uint32_t fused_hits = 0u;                                  // hits of this wave's chunks (fused level 0): one atomic per wave at the end
+  uint32_t my_children = 0u;                                 // fall: child rays traced by this wave (wave-uniform)
   const float inv_cells = 1.0f / (float)n_cells;
   const bool spawn_level = level < fp.max_depth;
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -564,7 +598,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // lit), so chunks are handed out dynamically; a single device counter sustains only ~88 atomics per microsecond
   // (a 4K frame's level 0 has 130k chunks), so the list is cut into NSTRIPE stripes with a cursor each: a wave works
   // through its home stripe, then moves to the stripe with the most chunks left.
-  const uint32_t n_chunks = (count + 63u) / 64u;
+  const uint32_t n_chunks = qin ? s_segfirst[NSEG] : (count + 63u) / 64u;
   const uint32_t cps = (n_chunks + NSTRIPE - 1) / NSTRIPE;         // chunks per stripe
   uint32_t stripe = (blockIdx.x * (BLOCK / 64) + wave) % NSTRIPE;
   // RT_DEBUG_STATS bit 1 << 20 (audit build): wave cycles per phase -> Counters::dbg (hit setup, light setup, sample loops, all)
@@ -581,7 +615,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       // with the most chunks left — one load and one atomic per move, one load to learn that the level is finished
       int left = 0;
       if (lane < (uint32_t)NSTRIPE) {
-        const uint32_t cur = __hip_atomic_load(&C->stripes[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cur = __hip_atomic_load(&stripes[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t first = lane * cps;
         const uint32_t n_s = first < n_chunks ? min(cps, n_chunks - first) : 0u;
         left = cur < n_s ? (int)(n_s - cur) : 0;
@@ -592,19 +626,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       if ((key >> 6) <= 0) return 0xFFFFFFFFu;
       stripe = 63u - (uint32_t)(key & 63);
       uint32_t j_ = 0;
-      if (lane == 0) j_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+      if (lane == 0) j_ = atomicAdd(&stripes[stripe * 32], 1u);
       i_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)j_);
     }
   };
   uint32_t chunk;
   {
     uint32_t j_ = 0;
-    if (lane == 0) j_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+    if (lane == 0) j_ = atomicAdd(&stripes[stripe * 32], 1u);
     chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)j_));
   }
   while (chunk != 0xFFFFFFFFu) {
-    const uint32_t h = chunk * 64u + lane;
+    uint32_t h = chunk * 64u + lane;
     bool active = h < count;
+    if (qin) {                                 // chunk -> (segment, offset): the last segment whose first chunk id is <= chunk
+      int lo_ = 0, hi_ = NSEG;
+      while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (s_segfirst[mid] <= chunk) lo_ = mid; else hi_ = mid; }
+      const uint32_t off = (chunk - s_segfirst[lo_]) * 64u + lane;
+      active = off < s_segn[lo_];
+      h = (uint32_t)lo_ * seg_cap + off;       // slot in the queue
+    }
     long long ck_t = prof ? clock64() : 0;
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
     v2f a_AB[MAXS], a_Cc[MAXS], a_Sg[(MAXS + 1) / 2];
@@ -637,22 +678,44 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         }
       }
       fused_hits += (uint32_t)__popcll(__ballot(active));
-    } else if (active) {
+    } else if (active && !qin) {
       hr = hits[h];
       r = load_ray(level, hr.slot, cam, fp.rs, q);
     }
     if (fused && !__any(active)) {             // a tile of background pixels: nothing to shade
       uint32_t nc_ = 0;
-      if (lane == 0) nc_ = atomicAdd(&C->stripes[stripe * 32], 1u);
+      if (lane == 0) nc_ = atomicAdd(&stripes[stripe * 32], 1u);
       chunk = steal((uint32_t)__builtin_amdgcn_readfirstlane((int)nc_));
       continue;
     }
     if (active) {
+      d3 n, hp;
+      if (qin) {
+        const HitRay hy = hin[h];
+        hp = mk3(hy.hp[0], hy.hp[1], hy.hp[2]);
+        r.d = mk3(hy.d[0], hy.d[1], hy.d[2]);
+        r.w = mk3((double)hy.w[0], (double)hy.w[1], (double)hy.w[2]);
+        r.lp = hy.pk & (HITRAY_MAX_PIXELS - 1u);
+        hr.prim = (int)((hy.pk >> HITRAY_PIX_BITS) & (nB > 0 ? 15u : 31u));
+        const Prim& op_ = P[hr.prim];
+        if (op_.type == 0) {                     // sphere.py:80-90 with the stored hit point
+          n = mk3((hp.x - op_.a[0]) / op_.a[3], (hp.y - op_.a[1]) / op_.a[3], (hp.z - op_.a[2]) / op_.a[3]);
+          if (dot3(r.d, n) > 0) n = mk3(-n.x, -n.y, -n.z);
+        } else if (op_.type == 1) n = plane_normal(op_, r.d);
+        else {                                   // the face cube.py:113-134 chose, kept by the lane that traced the ray
+          const uint32_t f_ = hy.pk >> 29;
+          const double sg_ = (f_ & 4u) ? 1.0 : -1.0;
+          n = mk3((f_ & 3u) == 0u ? sg_ : 0.0, (f_ & 3u) == 1u ? sg_ : 0.0, (f_ & 3u) == 2u ? sg_ : 0.0);
+        }
+        v = normalize_clamped(mkf((float)-r.d.x, (float)-r.d.y, (float)-r.d.z));       // (o - hp) / |o - hp| = -d
+      } else {
+        const Prim& op_ = P[hr.prim];
+        n = prim_normal(op_, r.o, r.d, hr.t);
+        hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
+        v = normalize_clamped(mkf((float)(r.o.x - hp.x), (float)(r.o.y - hp.y), (float)(r.o.z - hp.z)));
+      }
       const Prim& op = P[hr.prim];
-      const d3 n = prim_normal(op, r.o, r.d, hr.t);
-      const d3 hp = mk3(r.o.x + hr.t * r.d.x, r.o.y + hr.t * r.d.y, r.o.z + hr.t * r.d.z);
       p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);
-      v = normalize_clamped(mkf((float)(r.o.x - hp.x), (float)(r.o.y - hp.y), (float)(r.o.z - hp.z)));
       nf = tof(n);
       mat_idx = op.mat; own = hr.prim; own_is_plane = op.type == 1;
       lp = r.lp; gpix = global_pixel(fp.rs, lp);
@@ -669,7 +732,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     }
     // (all global loads of this chunk are done) fetch the next chunk's cursor and reserve the children's queue slots
     uint32_t next_cursor = 0;
-    if (lane == 0) next_cursor = atomicAdd(&C->stripes[stripe * 32], 1u);
+    if (lane == 0) next_cursor = atomicAdd(&stripes[stripe * 32], 1u);
     const double* mat_early = s_matd[mat_idx];
     const bool needT = spawn_level && active && (mat_early[10] > EPS);
     const bool needR = spawn_level && active && (mat_early[6] > EPS || mat_early[7] > EPS || mat_early[8] > EPS);
@@ -677,7 +740,49 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     const uint32_t nT = (uint32_t)__popcll(mT), nR = (uint32_t)__popcll(mR);
     const uint32_t seg = spawn_segment(chunk, count);
     uint32_t spawn_base = 0;
-    if (lane == 0 && nT + nR != 0u) spawn_base = atomicAdd(&C->segcnt[(level + 1) & 1][seg * 32], nT + nR);
+    unsigned long long mTh = 0ull, mRh = 0ull;       // fall: children that hit something
+    bool hitT = false, hitR = false;
+    if (fall) {
+      if (nT + nR != 0u) {
+        const uint32_t t_ = threadIdx.x;
+        // the child rays exactly as the queue path forms them (ray_tracer.py:565-595), traced by the lanes that spawn them:
+        // transmitted first, then reflected; a hit is kept (t, record, box face) in LDS until the end of the chunk, when its
+        // queue slot is known; a miss adds weight * background (ray_tracer.py:500-502) to the pixel together with the
+        // hit's own colour (at level 0 that is a plain store, which must not come after an atomic add of the child's term)
+        auto trace_child = [&](bool need, bool refl, bool* hit_) __attribute__((always_inline)) {
+          if (!need) return;
+          const d3 hp_ = mk3(s_geo[0][t_], s_geo[1][t_], s_geo[2][t_]), n_ = mk3(s_geo[3][t_], s_geo[4][t_], s_geo[5][t_]);
+          const d3 d_ = mk3(s_geo[6][t_], s_geo[7][t_], s_geo[8][t_]);
+          d3 oc_, dc_;
+          if (refl) {
+            const double dn = dot3(d_, n_);                                  // reflect_batch, :34-36
+            dc_ = mk3(d_.x - (2 * dn) * n_.x, d_.y - (2 * dn) * n_.y, d_.z - (2 * dn) * n_.z);
+            oc_ = mk3(hp_.x + n_.x * EPS, hp_.y + n_.y * EPS, hp_.z + n_.z * EPS);
+          } else {
+            dc_ = d_;
+            oc_ = mk3(hp_.x - n_.x * EPS, hp_.y - n_.y * EPS, hp_.z - n_.z * EPS);
+          }
+          int k_ = -1;
+          const double tc_ = nearest_coherent(P, nS, nP, nB, oc_, dc_, &k_, fp.plane_thr);
+          if (k_ >= 0) {
+            uint32_t face = 0u;
+            if (MAXB > 0 && P[k_].type == 2) {
+              d3 nb_; box_hit<true>(P[k_], oc_, dc_, &nb_);
+              face = nb_.x != 0.0 ? (nb_.x > 0 ? 4u : 0u) : (nb_.y != 0.0 ? (nb_.y > 0 ? 5u : 1u) : (nb_.z > 0 ? 6u : 2u));
+            }
+            s_ct[refl ? 1 : 0][t_] = tc_;
+            s_ck[refl ? 1 : 0][t_] = (uint32_t)k_ | (face << 8);
+            *hit_ = true;
+          }
+        };
+        if (nT != 0u) trace_child(needT, false, &hitT);
+        if (nR != 0u) trace_child(needR, true, &hitR);
+        my_children += nT + nR;
+        mTh = __ballot(hitT); mRh = __ballot(hitR);
+        const uint32_t nh_ = (uint32_t)__popcll(mTh) + (uint32_t)__popcll(mRh);
+        if (lane == 0 && nh_ != 0u) spawn_base = atomicAdd(&C->segcnt3[(level + 1) % 3][seg * 32], nh_);
+      }
+    } else if (lane == 0 && nT + nR != 0u) spawn_base = atomicAdd(&C->segcnt[(level + 1) & 1][seg * 32], nT + nR);
     bool near_scene = true;    // |oc|^2 within 1000 r^2 of every sphere (see the umbra claim below)
     uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
     float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
@@ -1114,13 +1219,56 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       if (seq_background_term(fp, level, mat)) {                             // ray_tracer.py:370-377
         b0 = (float)(sc.bg[0] * mat[10]); b1 = (float)(sc.bg[1] * mat[10]); b2 = (float)(sc.bg[2] * mat[10]);
       }
-      const float c0 = wgt.x * ((dif0 + spc0) * one_m + b0), c1 = wgt.y * ((dif1 + spc1) * one_m + b1),
-                  c2 = wgt.z * ((dif2 + spc2) * one_m + b2);
+      float c0 = wgt.x * ((dif0 + spc0) * one_m + b0), c1 = wgt.y * ((dif1 + spc1) * one_m + b1),
+            c2 = wgt.z * ((dif2 + spc2) * one_m + b2);
+      if (fall) {                              // children that left the scene: weight * background (ray_tracer.py:500-502)
+        const uint32_t t_ = threadIdx.x;
+        if (needT && !hitT) {
+          c0 += (float)((s_geo[9][t_] * mat[10]) * sc.bg[0]); c1 += (float)((s_geo[10][t_] * mat[10]) * sc.bg[1]); c2 += (float)((s_geo[11][t_] * mat[10]) * sc.bg[2]);
+        }
+        if (needR && !hitR) {
+          c0 += (float)((s_geo[9][t_] * mat[6]) * sc.bg[0]); c1 += (float)((s_geo[10][t_] * mat[7]) * sc.bg[1]); c2 += (float)((s_geo[11][t_] * mat[8]) * sc.bg[2]);
+        }
+      }
       float* dst = fb + 3 * (size_t)lp;
       if (level == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
       else { atomicAdd(dst + 0, c0); atomicAdd(dst + 1, c1); atomicAdd(dst + 2, c2); }
     }
     const long long ck_s1 = prof ? clock64() : 0;
+    if (fall) {
+      if ((mTh | mRh) != 0ull) {
+        const uint32_t base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)spawn_base);
+        const uint32_t nTh = (uint32_t)__popcll(mTh);
+        const uint32_t oT = base_ + __builtin_amdgcn_mbcnt_hi((uint32_t)(mTh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mTh, 0u));
+        const uint32_t oR = base_ + nTh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mRh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mRh, 0u));
+        const uint32_t t_ = threadIdx.x;
+        auto put_child = [&](bool refl, uint32_t o_) __attribute__((always_inline)) {
+          if (o_ >= seg_cap) { C->overflow = 1u; return; }
+          const d3 hp_ = mk3(s_geo[0][t_], s_geo[1][t_], s_geo[2][t_]), n_ = mk3(s_geo[3][t_], s_geo[4][t_], s_geo[5][t_]);
+          const d3 d_ = mk3(s_geo[6][t_], s_geo[7][t_], s_geo[8][t_]);
+          d3 oc_, dc_;
+          if (refl) {
+            const double dn = dot3(d_, n_);
+            dc_ = mk3(d_.x - (2 * dn) * n_.x, d_.y - (2 * dn) * n_.y, d_.z - (2 * dn) * n_.z);
+            oc_ = mk3(hp_.x + n_.x * EPS, hp_.y + n_.y * EPS, hp_.z + n_.z * EPS);
+          } else {
+            dc_ = d_;
+            oc_ = mk3(hp_.x - n_.x * EPS, hp_.y - n_.y * EPS, hp_.z - n_.z * EPS);
+          }
+          const double tc_ = s_ct[refl ? 1 : 0][t_];
+          const uint32_t kf_ = s_ck[refl ? 1 : 0][t_];
+          HitRay y;
+          y.hp[0] = oc_.x + tc_ * dc_.x; y.hp[1] = oc_.y + tc_ * dc_.y; y.hp[2] = oc_.z + tc_ * dc_.z;
+          y.d[0] = dc_.x; y.d[1] = dc_.y; y.d[2] = dc_.z;
+          y.w[0] = (float)(s_geo[9][t_] * (refl ? mat[6] : mat[10])); y.w[1] = (float)(s_geo[10][t_] * (refl ? mat[7] : mat[10]));
+          y.w[2] = (float)(s_geo[11][t_] * (refl ? mat[8] : mat[10]));
+          y.pk = MAXB > 0 ? (lp | ((kf_ & 15u) << HITRAY_PIX_BITS) | ((kf_ >> 8) << 29)) : (lp | ((kf_ & 31u) << HITRAY_PIX_BITS));
+          hout[(size_t)seg * seg_cap + o_] = y;
+        };
+        if (hitT) put_child(false, oT);
+        if (hitR) put_child(true, oR);
+      }
+    } else
     if (nT + nR != 0u) {                                                   // ray_tracer.py:565-595
       const uint32_t base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)spawn_base);
       const uint32_t seg_cap = fp.queue_cap / NSEG;
@@ -1154,6 +1302,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     if (prof) ck_sync += clock64() - ck_s1;
   }
   if (fused && lane == 0 && fused_hits != 0u) atomicAdd(&C->n_hits[0], fused_hits);
+  if (fall && lane == 0 && my_children != 0u) atomicAdd(&C->n_rays[level + 1], my_children);
   if (prof && lane == 0) {
     atomicAdd(&C->queries, (unsigned long long)ck_sync);
     atomicAdd(&C->dbg[0], (unsigned long long)ck_hit); atomicAdd(&C->dbg[1], (unsigned long long)ck_setup);

@@ -27,10 +27,25 @@ def algorithmic_flops(*, n_sph, n_pln, n_box, n_lights, n_shadow, rays, hits, ch
             hits * (PER_HIT + n_lights * PER_HIT_LIGHT + n_lights * cells * PER_SHADOW_RAY) + PER_CHILD * children)
 
 
-def shade_kernel_flops(*, n_sph, n_pln, n_box, n_lights, n_shadow, hits, segments=0):
+def shade_kernel_flops(*, n_sph, n_pln, n_box, n_lights, n_shadow, hits, segments=0, rays=0, children=0):
     """The share of the model executed by the shade kernel for `hits` hits (its launch's
-    algorithmic flops): shadow queries + per-hit shading terms."""
+    algorithmic flops): shadow queries + per-hit shading terms — plus, for the radiance rays the kernel
+    traces itself (fused frames: `rays` of them, `children` spawned), their nearest-hit queries, winner
+    normals and the spawn arithmetic, i.e. the whole of algorithmic_flops() when every level is fused."""
     cells = n_shadow * n_shadow if n_shadow > 1 else 1
     shadow = hits * n_lights * cells
-    return ((shadow + max(segments, 0)) * flops_per_query(n_sph, n_pln, n_box) +
+    return ((shadow + max(segments, 0) + rays) * flops_per_query(n_sph, n_pln, n_box) + PER_RAY * rays + PER_CHILD * children +
             hits * (PER_HIT + n_lights * PER_HIT_LIGHT + n_lights * cells * PER_SHADOW_RAY))
+
+
+def rays_traced_by_shade_kernel(stats):
+    """(rays, children) whose nearest-hit queries ran inside the shade kernel, from an rt_stats dict of a frame rendered
+    with RT_FLAG_TIMING: no k_trace launch at all -> every ray; one launch fewer than levels -> the camera rays."""
+    levels = [r for r in stats["level_rays"] if r > 0]
+    if not levels:
+        return 0, 0
+    if stats["trace_launches"] == 0:
+        return int(stats["rays"]), int(stats["rays"]) - int(stats["level_rays"][0])
+    if stats["trace_launches"] < stats["levels"]:
+        return int(stats["level_rays"][0]), 0
+    return 0, 0

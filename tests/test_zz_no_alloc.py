@@ -137,13 +137,16 @@ def test_static_entry_runs_under_graph_capture_and_reports_async_overflow():
         del g
         gs.set_stream(None)
         gs.sync()                                             # the captured frame's counters: no overflow
-    # An async static frame that cannot fit: the camera sits inside a sphere that is transparent AND reflective, so every
-    # pixel's hit spawns two children: level 1 holds 2 rays per pixel, the static queues ~1.3 at the maximum row-set size.
+    # An async static frame that cannot fit: the camera sits inside a sphere that is transparent AND reflective, inside a
+    # larger opaque one, so every pixel's hit spawns two children that both hit something: level 1 holds 2 rays (and 2
+    # hits) per pixel, the static queues ~1.3 at the maximum row-set size.
     from raytracer_amd import parse_scene_text, separate_objects
     text = """cam 0 0 0  0 0 1  0 1 0  1 2
 set 0.2 0.3 0.4 1 3
 mtl 0.5 0.5 0.5 1 1 1 0.5 0.5 0.5 10 0.5
+mtl 0.4 0.6 0.5 0.5 0.5 0.5 0 0 0 10 0
 sph 0 0 0 10 1
+sph 0 0 0 20 2
 lgt 0 5 0 1 1 1 1 0.5 1
 """
     cam2, st2, objs = parse_scene_text(text)

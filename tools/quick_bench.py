@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 
 from bench import WORKLOADS, load_workload, PEAK_TFLOPS  # noqa: E402
 from raytracer_amd import _lib  # noqa: E402
-from raytracer_amd.flops import shade_kernel_flops  # noqa: E402
+from raytracer_amd.flops import shade_kernel_flops, rays_traced_by_shade_kernel  # noqa: E402
 from raytracer_amd.packing import pack_scene  # noqa: E402
 from raytracer_amd.render import GpuScene  # noqa: E402
 
@@ -53,8 +53,9 @@ def main():
             s = gs.last_stats
             if best is None or s["total_ms"] < best["total_ms"]:
                 best = dict(s, wall_ms=wall)
+        fr_, fc_ = rays_traced_by_shade_kernel(best)
         flops = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
-                                   hits=best["hits"], segments=max(best["segments"], 0))
+                                   hits=best["hits"], segments=max(best["segments"], 0), rays=fr_, children=fc_)
         rays = best["rays"] + best["shadow_rays"]
         out = {"workload": (desc if args.scale == 1 else f"{desc} /{args.scale}") + (" [RT_FLAG_BRUTE_FORCE]" if args.brute else ""), "frame_ms": round(best["total_ms"], 3),
                "shade_ms": round(best["shade_ms"], 3), "trace_ms": round(best["trace_ms"], 3), "other_ms": round(best["other_ms"], 3),
