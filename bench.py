@@ -321,13 +321,25 @@ def main():
                          "launches_per_frame": b_launches, "achieved": round(b_ach, 3), "frac": round(b_ach / peak, 4),
                          "rays_equal": int(bs[0].rays) == int(last.rays) and int(bs[0].hits) == int(last.hits)}
             traffic = None
+            traffic_frame = None
             executed = None      # counted instructions / flops of the same launches from the committed PMC pass (profiles/)
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     rec = json.load(open(pmc)).get(args.workload, {})
                     traffic = rec.get("hbm_bytes_per_shade_launch")
-                    if world == 1 and rec.get("executed_fp32_flops_per_frame"):
+                    traffic_frame = rec.get("hbm_bytes_per_frame")
+                    if world == 1 and precision == "fp64" and rec.get("executed_fp64_flops_per_frame"):
+                        ex = rec["executed_fp64_flops_per_frame"] / (shade_ms * 1e-3) / 1e12
+                        issue_peak = rec.get("valu_issue_peak_Tinstr_per_s")
+                        executed = {"tflops": round(ex, 2), "frac": round(ex / peak, 4),
+                                    "valu_wave_instructions_per_frame": rec.get("valu_wave_instructions_per_frame"),
+                                    "valu_issue_fraction_of_measured_peak": round(rec["valu_wave_instructions_per_frame"] / (shade_ms * 1e-3) / 1e12 / issue_peak, 4)
+                                    if issue_peak and rec.get("valu_wave_instructions_per_frame") else None,
+                                    "valu_active_fraction_of_wave_cycles": rec.get("valu_active_fraction_of_wave_cycles"),
+                                    "round": rec.get("round"), "source": rec.get("source", "profiles/pmc_latest.json (rocprofv3 --pmc)"),
+                                    "note": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes (FMA = 2) of the shade launches / their time"}
+                    if world == 1 and precision == "fp32" and rec.get("executed_fp32_flops_per_frame"):
                         ex = rec["executed_fp32_flops_per_frame"] / (shade_ms * 1e-3) / 1e12
                         ex_hi = rec.get("executed_fp32_flops_per_frame_upper", rec["executed_fp32_flops_per_frame"]) / (shade_ms * 1e-3) / 1e12
                         issue_peak = rec.get("valu_issue_peak_Tinstr_per_s")
@@ -355,7 +367,8 @@ def main():
             roofline = {"bound": "valu", "kernel": kernel,
                         "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d): every query tests every surface",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac, "frac_basis": basis,
-                        "traffic": traffic, "brute_force": brute, "culled": culled, "executed": executed,
+                        "traffic": traffic, "traffic_per_frame": traffic_frame, "algorithmic_bytes_per_frame": int(W * H * 3 * (4 if precision == "fp32" else 8)),
+                        "brute_force": brute, "culled": culled, "executed": executed,
                         "flops_per_launch": flops_frame / launches, "frames_with_events": len(timed),
                         "rays_traced_in_shade_kernel": fused_rays,
                         "trace_ms_per_step": round(trace_ms, 4), "flops_per_query": flops_per_query(n_sph, n_pln, n_box)}
@@ -376,6 +389,7 @@ def main():
         }
         if world > 1 and roofline is not None:
             roofline["traffic"] = None      # the PMC pass (profiles/) measured full-frame launches on one GPU
+            roofline["traffic_per_frame"] = None
         if verify is not None:
             out["verify"] = verify
         if multi is not None:

@@ -438,7 +438,7 @@ __device__ __forceinline__ float ls_light_sum_simple(v2f (&AB)[NS], v2f (&Cc)[NS
 #ifndef LS_WAVES
 #define LS_WAVES 2
 #endif
-template <int MAXS, int MAXP, int MAXB, bool OPAQUE>
+template <int MAXS, int MAXP, int MAXB, bool OPAQUE, bool FALL = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES))) void k_shade_ls(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                     RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                     float* __restrict__ fb, FixRec* __restrict__ fix) {
@@ -474,12 +474,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // after its query too): a chunk is 64 pixels — an 8x8 tile —, every lane forms its camera ray, runs the literal fp64
   // nearest() over the staged records and shades its own hit.  No k_trace launch, no 16-byte HitRec per pixel written and
   // read back, no global load at the start of a chunk; pixels that miss get the background here.
-  const bool fused = level == 0 && fp.fuse0 != 0u;
+  const bool fused = level == 0 && (FALL || fp.fuse0 != 0u);
   // fp.fuse0 == 2: the frame has no k_trace launch at all.  The children of a chunk's hits are traced by the lanes that
   // spawn them (right after the hit's geometry is known, before the light loop), misses add their background term, and
   // the HITS are appended — ray and hit in one 64-byte HitRay — to the next level's queue, which the next launch of this
   // kernel reads instead of HitRec + ray queue.  ray_tracer.py:491-595 as one kernel per level.
-  const bool fall = fp.fuse0 == 2u;
+  // (FALL is a template parameter so that the instantiation for fused frames carries none of the queue path's arguments
+  // and code: ten pointers per ray queue, HitRec loads, slot reservations)
+  constexpr bool fall = FALL;
   const HitRay* __restrict__ hin = reinterpret_cast<const HitRay*>(q.ox);
   HitRay* __restrict__ hout = reinterpret_cast<HitRay*>(nq.ox);
   uint32_t* const stripes = fall ? C->stripes3[level % 3] : C->stripes;
@@ -1327,9 +1329,14 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
   if (!shade_ls_serves(ds, fp)) return false;
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
-    if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
+    if (fp.fuse0 == 2u) {                                                                                           \
+      if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
+                                     cur, nxt, hits, C, fb, fix);                                                    \
+      else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, \
+                              nxt, hits, C, fb, fix);                                                                \
+    } else if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
                                    cur, nxt, hits, C, fb, fix);                                                      \
-    else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur,  \
+    else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur,  \
                             nxt, hits, C, fb, fix);                                                                  \
     return true;                                                                                                    \
   } while (0)

@@ -14,7 +14,7 @@ from conftest import ROOT
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
 def test_headline_kernel_keeps_two_waves_per_simd():
-    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), "rt::k_shade_ls<6, 2, 0, true>", "rt_shade_ls.hpp"],
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), "rt::k_shade_ls<6, 2, 0, true, true>", "rt_shade_ls.hpp"],
                          capture_output=True, text=True, timeout=600).stdout
     occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", out)
     spill = re.search(r"VGPRs Spill: (\d+)", out)

@@ -15,6 +15,10 @@ amf = tot("SQ_INSTS_VALU_ADD_F32") + tot("SQ_INSTS_VALU_MUL_F32") + 2 * tot("SQ_
 lower = 64 * (amf + tot("SQ_INSTS_VALU_TRANS_F32"))
 upper = 64 * (2 * amf + tot("SQ_INSTS_VALU_TRANS_F32"))
 f64 = 64 * (tot("SQ_INSTS_VALU_ADD_F64") + tot("SQ_INSTS_VALU_MUL_F64") + 2 * tot("SQ_INSTS_VALU_FMA_F64"))
+# HBM bytes of the whole frame: every kernel's bytes per launch x its launches per frame (FETCH_SIZE doubled as summarize_pmc.py does)
+frame_bytes = sum(v.get("hbm_bytes_per_launch", 0.0) * v.get("launches_per_frame", 0.0) for v in d["kernels"].values())
+per_kernel = {k.replace("rt::", "").split("<")[0]: round(v.get("hbm_bytes_per_launch", 0.0) * v.get("launches_per_frame", 0.0))
+              for k, v in d["kernels"].items() if v.get("hbm_bytes_per_launch")}
 path = "profiles/pmc_latest.json"
 try:
     out = json.load(open(path))
@@ -22,6 +26,8 @@ except Exception:
     out = {}
 out[workload] = {
     "hbm_bytes_per_shade_launch": d.get("hbm_bytes_per_shade_launch"),
+    "hbm_bytes_per_frame": frame_bytes,
+    "hbm_bytes_per_frame_by_kernel": per_kernel,
     "executed_fp32_flops_per_frame": lower,
     "executed_fp32_flops_per_frame_upper": upper,
     "packed_static_share_of_fp32_add_mul_fma": share,
