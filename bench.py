@@ -326,7 +326,16 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    rec = json.load(open(pmc)).get(args.workload, {})
+                    pmc_all = json.load(open(pmc))
+                    rec = pmc_all.get(args.workload, {})
+                    rec_b = pmc_all.get(args.workload + "_brute", {})
+                    if brute is not None and rec_b.get("valu_wave_instructions_per_frame") and rec_b.get("valu_issue_peak_Tinstr_per_s"):
+                        # the brute-force launches' own counters (a separate rocprofv3 --pmc pass over quick_bench.py --brute)
+                        brute["valu_wave_instructions_per_frame"] = rec_b["valu_wave_instructions_per_frame"]
+                        brute["valu_issue_fraction_of_measured_peak"] = round(
+                            rec_b["valu_wave_instructions_per_frame"] / (brute["shade_ms"] * 1e-3) / 1e12 / rec_b["valu_issue_peak_Tinstr_per_s"], 4)
+                        brute["model_flops_per_valu_lane_instruction"] = round(flops_frame / (64.0 * rec_b["valu_wave_instructions_per_frame"]), 4)
+                        brute["pmc_source"] = rec_b.get("source")
                     traffic = rec.get("hbm_bytes_per_shade_launch")
                     traffic_frame = rec.get("hbm_bytes_per_frame")
                     if world == 1 and precision == "fp64" and rec.get("executed_fp64_flops_per_frame"):

@@ -438,7 +438,7 @@ __device__ __forceinline__ float ls_light_sum_simple(v2f (&AB)[NS], v2f (&Cc)[NS
 #ifndef LS_WAVES
 #define LS_WAVES 2
 #endif
-template <int MAXS, int MAXP, int MAXB, bool OPAQUE, bool FALL = false>
+template <int MAXS, int MAXP, int MAXB, bool OPAQUE, int FALL = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES))) void k_shade_ls(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                     RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                     float* __restrict__ fb, FixRec* __restrict__ fix) {
@@ -474,14 +474,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // after its query too): a chunk is 64 pixels — an 8x8 tile —, every lane forms its camera ray, runs the literal fp64
   // nearest() over the staged records and shades its own hit.  No k_trace launch, no 16-byte HitRec per pixel written and
   // read back, no global load at the start of a chunk; pixels that miss get the background here.
-  const bool fused = level == 0 && (FALL || fp.fuse0 != 0u);
+  const bool fused = FALL == 2 ? true : FALL == 3 ? false : (level == 0 && (FALL != 0 || fp.fuse0 != 0u));
   // fp.fuse0 == 2: the frame has no k_trace launch at all.  The children of a chunk's hits are traced by the lanes that
   // spawn them (right after the hit's geometry is known, before the light loop), misses add their background term, and
   // the HITS are appended — ray and hit in one 64-byte HitRay — to the next level's queue, which the next launch of this
   // kernel reads instead of HitRec + ray queue.  ray_tracer.py:491-595 as one kernel per level.
-  // (FALL is a template parameter so that the instantiation for fused frames carries none of the queue path's arguments
-  // and code: ten pointers per ray queue, HitRec loads, slot reservations)
-  constexpr bool fall = FALL;
+  // (FALL is a template parameter so that the instantiations for fused frames carry none of the queue path's arguments
+  // and code: ten pointers per ray queue, HitRec loads, slot reservations.  0: frames with k_trace launches; 2: level 0
+  // of a fused frame; 3: its deeper levels; 1: any level of a fused frame)
+  constexpr bool fall = FALL != 0;
   const HitRay* __restrict__ hin = reinterpret_cast<const HitRay*>(q.ox);
   HitRay* __restrict__ hout = reinterpret_cast<HitRay*>(nq.ox);
   uint32_t* const stripes = fall ? C->stripes3[level % 3] : C->stripes;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   const uint32_t seg_cap = fp.queue_cap / NSEG;
   if (!fused && !fall && C->n_hits[level] == 0u) return;        // (uniform over the grid: an empty level)
   if (fall) {
-    if (level >= 1 && threadIdx.x < 64) {          // lane q: segment q; inclusive scans over the wave (as in k_trace)
+    if (FALL != 2 && level >= 1 && threadIdx.x < 64) {          // lane q: segment q; inclusive scans over the wave (as in k_trace)
       const uint32_t raw = C->segcnt3[level % 3][threadIdx.x * 32];
       const uint32_t nq_ = min(raw, seg_cap);
       uint32_t ch = (nq_ + 63u) / 64u, tot = nq_, worst = raw;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   const int nS = sc.nS, nP = sc.nP, nB = sc.nB;
   float umbra_t0_max = 3.0e38f;                              // 1000 * (smallest sphere radius)^2
   for (int k = 0; k < nS; ++k) umbra_t0_max = fminf(umbra_t0_max, 1000.0f * s_sphf[k].w * s_sphf[k].w);
-  const bool qin = fall && level >= 1;                       // this level's hits come from the HitRay queue
+  const bool qin = FALL == 2 ? false : FALL == 3 ? true : (fall && level >= 1);                       // this level's hits come from the HitRay queue
   uint32_t count = fused ? C->n_rays[0] : (qin ? s_segfirst[NSEG] * 64u : C->n_hits[level]);
   if (!qin && count > fp.hit_cap) count = fp.hit_cap;
   uint32_t fused_hits = 0u;                                  // hits of this wave's chunks (fused level 0): one atomic per wave at the end
@@ -1327,17 +1328,17 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
                             RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
                             hipStream_t st) {
   if (!shade_ls_serves(ds, fp)) return false;
+#define RT_LS_K(S, Pn, B, O, F)                                                                                       \
+  hipLaunchKernelGGL((k_shade_ls<S, Pn, B, O, F>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, hits, C, fb, fix)
+  // fused frames (fp.fuse0 == 2): one instantiation for level 0 (camera rays, no queue input) and one for the levels that
+  // read the HitRay queue — neither carries the other's arguments and code
 #define RT_LS(S, Pn, B)                                                                                             \
   do {                                                                                                              \
     if (fp.fuse0 == 2u) {                                                                                           \
-      if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
-                                     cur, nxt, hits, C, fb, fix);                                                    \
-      else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false, true>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, \
-                              nxt, hits, C, fb, fix);                                                                \
-    } else if (opaque) hipLaunchKernelGGL((k_shade_ls<S, Pn, B, true, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, \
-                                   cur, nxt, hits, C, fb, fix);                                                      \
-    else hipLaunchKernelGGL((k_shade_ls<S, Pn, B, false, false>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur,  \
-                            nxt, hits, C, fb, fix);                                                                  \
+      if (opaque) { if (level == 0) RT_LS_K(S, Pn, B, true, 2); else RT_LS_K(S, Pn, B, true, 3); }                  \
+      else { if (level == 0) RT_LS_K(S, Pn, B, false, 2); else RT_LS_K(S, Pn, B, false, 3); }                       \
+    } else if (opaque) RT_LS_K(S, Pn, B, true, 0);                                                                  \
+    else RT_LS_K(S, Pn, B, false, 0);                                                                               \
     return true;                                                                                                    \
   } while (0)
   if (ds.nB == 0) {
@@ -1358,6 +1359,7 @@ static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& ca
     // k_shade_fast for pool + 2 boxes at 4K)
   }
 #undef RT_LS
+#undef RT_LS_K
   return false;
 }
 

@@ -13,17 +13,18 @@ from conftest import ROOT
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
-def test_headline_kernel_keeps_two_waves_per_simd():
-    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), "rt::k_shade_ls<6, 2, 0, true, true>", "rt_shade_ls.hpp"],
+@pytest.mark.parametrize("fall,max_spill", [(2, 12), (3, 4)])      # level 0 / deeper levels of a fused frame
+def test_headline_kernel_keeps_two_waves_per_simd(fall, max_spill):
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), f"rt::k_shade_ls<6, 2, 0, true, {fall}>", "rt_shade_ls.hpp"],
                          capture_output=True, text=True, timeout=600).stdout
     occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", out)
     spill = re.search(r"VGPRs Spill: (\d+)", out)
     vgprs = re.search(r" VGPRs: (\d+)", out)
     assert occ and vgprs and spill, out
     assert int(occ.group(1)) >= 2, out
-    # (round 3, with the level-0 query fused in: 8 loop-invariant values are parked in scratch before the chunk loop and
-    # re-read once per 64-hit chunk, outside the light and sample loops)
-    assert int(spill.group(1)) <= 8, out
+    # (round 3, with the level-0 query fused in: ~10 loop-invariant values are parked in scratch before the chunk loop and
+    # re-read once per 64-hit chunk, outside the light and sample loops; the deeper levels' instantiation spills nothing)
+    assert int(spill.group(1)) <= max_spill, out
     assert int(vgprs.group(1)) <= 256
 
 

@@ -3,6 +3,9 @@
 RT_FLAG_TIMING and prints per-kernel-class milliseconds (HIP events on the library's stream).
 
     python tools/quick_bench.py [workload] [--frames N] [--check]
+Frames go into a device buffer (hipMalloc through ctypes) back to back, as in bench.py's timed region: with a host copy
+of the image after every frame the GPU idles for tens of milliseconds between frames, its clocks drop and the same
+kernels measure ~9 % slower (--host-out keeps that behaviour).
 """
 import argparse
 import json
@@ -33,6 +36,7 @@ def main():
     ap.add_argument("--depth", type=int, default=None, help="override the recursion cap")
     ap.add_argument("--brute", action="store_true", help="RT_FLAG_BRUTE_FORCE frames: every surface tested for every shadow sample (the flop model's work; "
                                                          "the run profiles/r03_*_brute_kernel_stats.csv comes from)")
+    ap.add_argument("--host-out", action="store_true", help="copy every frame to the host (GPU idles between frames)")
     args = ap.parse_args()
     cam, st, mats, surfs, lights, W, H, precision, desc = load_workload(args.workload)
     W //= args.scale; H //= args.scale
@@ -44,15 +48,27 @@ def main():
     cam.setup(W / H)
     packed = pack_scene(mats, surfs, lights, st.background_color)
     n_sph, n_pln, n_box = packed.counts
+    dev_ptr = None
+    if not args.host_out:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        p = ctypes.c_void_p()
+        rc = hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(W * H * 3 * (4 if precision == "fp32" else 8)))
+        if rc != 0 or not p.value:
+            raise SystemExit(f"hipMalloc failed ({rc})")
+        dev_ptr = p.value
     with GpuScene(packed) as gs:
         best = None
+        flags = _lib.RT_FLAG_TIMING | (_lib.RT_FLAG_BRUTE_FORCE if args.brute else 0)
         for f in range(args.frames):
             t0 = time.perf_counter()
-            img = gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, flags=_lib.RT_FLAG_TIMING | (_lib.RT_FLAG_BRUTE_FORCE if args.brute else 0))
+            img = gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, flags=flags, out_ptr=dev_ptr)
             wall = (time.perf_counter() - t0) * 1e3
             s = gs.last_stats
             if best is None or s["total_ms"] < best["total_ms"]:
                 best = dict(s, wall_ms=wall)
+        if dev_ptr is not None:
+            img = gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, flags=flags)
         fr_, fc_ = rays_traced_by_shade_kernel(best)
         flops = shade_kernel_flops(n_sph=n_sph, n_pln=n_pln, n_box=n_box, n_lights=len(lights), n_shadow=n_shadow,
                                    hits=best["hits"], segments=max(best["segments"], 0), rays=fr_, children=fc_)
