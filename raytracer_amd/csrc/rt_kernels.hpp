@@ -165,6 +165,48 @@ __device__ __forceinline__ uint32_t grab64(uint32_t* cursor) {
   return __shfl(base, 0);
 }
 
+// 64-hit chunks of a level's hit list, handed out through NSTRIPE striped cursors (Counters::stripes; the level's trace
+// kernel zeroes them): a single device counter sustains only ~88 atomics per microsecond and every wave waits ~1-2 us
+// for its answer — a 1080p level has 27k chunks.  A wave works through its home stripe, then moves to the stripe with the
+// most chunks left (one load and one atomic per move).  fetch() issues the atomic for the NEXT chunk — call it right
+// after the current chunk's global loads —, take() consumes the answer at the chunk's end.  (k_shade_ls has the same
+// scheme inline.)  All lanes of the wave must call both.
+struct ChunkCursor {
+  static constexpr uint32_t NONE = 0xFFFFFFFFu;
+  uint32_t* stripes;
+  uint32_t n_chunks, cps, stripe;
+  __device__ __forceinline__ void init(uint32_t* s, uint32_t count, uint32_t wave_id) {
+    stripes = s; n_chunks = (count + 63u) / 64u; cps = (n_chunks + NSTRIPE - 1) / NSTRIPE; stripe = wave_id % NSTRIPE;
+  }
+  __device__ __forceinline__ uint32_t fetch() const {
+    uint32_t j = 0;
+    if (__lane_id() == 0) j = atomicAdd(&stripes[stripe * 32], 1u);
+    return j;
+  }
+  __device__ __forceinline__ uint32_t take(uint32_t fetched) {
+    const uint32_t lane = __lane_id();
+    uint32_t i_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)fetched);
+    for (;;) {
+      if (i_ < cps && stripe * cps + i_ < n_chunks) return stripe * cps + i_;
+      int left = 0;
+      if (lane < (uint32_t)NSTRIPE) {       // lane s looks at stripe s (device-scope load: not from this CU's vector cache)
+        const uint32_t cur = __hip_atomic_load(&stripes[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t first = lane * cps;
+        const uint32_t n_s = first < n_chunks ? min(cps, n_chunks - first) : 0u;
+        left = cur < n_s ? (int)(n_s - cur) : 0;
+      }
+      int key = (left << 6) | (int)(63u - lane);     // most chunks left, lowest stripe on ties
+#pragma unroll
+      for (int o_ = 32; o_ > 0; o_ >>= 1) key = max(key, __shfl_xor(key, o_));
+      if ((key >> 6) <= 0) return NONE;
+      stripe = 63u - (uint32_t)(key & 63);
+      uint32_t j_ = 0;
+      if (lane == 0) j_ = atomicAdd(&stripes[stripe * 32], 1u);
+      i_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)j_);
+    }
+  }
+};
+
 template <typename FB>
 __device__ __forceinline__ void fb_add(FB* fb, uint32_t lp, double r, double g, double b) {
   atomicAdd(&fb[3 * (size_t)lp + 0], (FB)r);
@@ -862,17 +904,21 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
   uint32_t count = C->n_hits[level];
   if (count > fp.hit_cap) count = fp.hit_cap;
   const uint32_t lane = __lane_id();
-  for (;;) {
-    uint32_t base = grab64(&C->work_shade[level]);
-    if (base >= count) break;
+  ChunkCursor cc; cc.init(C->stripes, count, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+  for (uint32_t chunk = cc.take(cc.fetch()); chunk != ChunkCursor::NONE;) {
+    const uint32_t base = chunk * 64u;
     uint32_t h = base + lane;
     bool active = h < count;
     RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0);
     const double* mat = sc.mats;
     r.d = r.o = r.w = mk3(0, 0, 0); r.lp = 0;
+    HitRec hr; hr.slot = 0; hr.prim = 0; hr.t = 0.0;
     if (active) {
-      const HitRec hr = hits[h];
+      hr = hits[h];
       r = load_ray(level, hr.slot, cam, fp.rs, q);
+    }
+    const uint32_t next_chunk = cc.fetch();      // (answered while this chunk is shaded)
+    if (active) {
       JitPixelKeyed jit; jit.seed = fp.seed; jit.gpix = global_pixel(fp.rs, r.lp); jit.depth = (uint32_t)level;
       int queries = 0;
       ExactHit e = shade_hit_exact(sc, P, r, hr, fp.n_shadow, jit, &queries, fp.sequential != 0, fp.plane_thr, &ac);
@@ -884,6 +930,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
       atomicAdd(&C->queries, (unsigned long long)queries);
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
+    chunk = cc.take(next_chunk);
   }
 }
 
@@ -896,8 +943,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact(DevScene sc, DevCamera ca
 // LDS and each listed hit's lane adds its own n^2 terms left to right.  Per sample AND per sum the arithmetic and its
 // order are those of soft_shadow_exact: results are bit-identical to k_shade_exact's.
 constexpr int ITEM_CHUNK = 512;
+#ifndef EXACT_ITEMS_WAVES
+#define EXACT_ITEMS_WAVES 3      // 168 VGPRs (35 spilled): the fp64 chains are latency bound, 3 waves per SIMD measured 10 % faster than 2
+#endif
 template <typename FB>
-__global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(EXACT_ITEMS_WAVES))) void k_shade_exact_items(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                              RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
                                                              FB* __restrict__ fb) {
   __shared__ Prim s_prims[LDS_PRIMS];
@@ -920,9 +970,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCam
   const int hits_per_chunk = max(1, ITEM_CHUNK / n_cells);       // (launch_frame uses this kernel for n^2 <= ITEM_CHUNK only)
   const bool seq = fp.sequential != 0;
   unsigned long long my_queries = 0ull;
-  for (;;) {
-    const uint32_t base = grab64(&C->work_shade[level]);
-    if (base >= count) break;
+  ChunkCursor cc; cc.init(C->stripes, count, blockIdx.x * (BLOCK / 64) + wave);
+  for (uint32_t chunk = cc.take(cc.fetch()); chunk != ChunkCursor::NONE;) {
+    const uint32_t base = chunk * 64u;
     const uint32_t h = base + lane;
     bool active = h < count;
     RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0), v = mk3(0, 0, 0), p = mk3(0, 0, 0);
@@ -940,7 +990,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCam
       active = active && k_ >= 0;
       const unsigned long long mh = __ballot(active);
       fused_hits += (uint32_t)__popcll(mh);
-      if (mh == 0ull) continue;                // a tile of background pixels
+      if (mh == 0ull) { chunk = cc.take(cc.fetch()); continue; }       // a tile of background pixels
       if (k_ < 0) {                            // a lane without a hit of its own shades a copy of a neighbour's (results dropped)
         const int srcl = __ffsll((long long)mh) - 1;
         hr.prim = __shfl(hr.prim, srcl); hr.t = __shfl(hr.t, srcl);
@@ -951,6 +1001,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCam
       hr = hits[active ? h : count - 1];
       r = load_ray(level, hr.slot, cam, fp.rs, q);
     }
+    const uint32_t next_chunk = cc.fetch();      // (answered while this chunk is shaded)
     {
       const Prim& pr = P[hr.prim];
       n = prim_normal(pr, r.o, r.d, hr.t);
@@ -1051,6 +1102,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_exact_items(DevScene sc, DevCam
       fb_put(fb, level == 0, r.lp, r.w.x * c0, r.w.y * c1, r.w.z * c2);                  // :563
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
+    chunk = cc.take(next_chunk);
   }
   for (int o_ = 32; o_ > 0; o_ >>= 1) my_queries += __shfl_xor(my_queries, o_);
   if (lane == 0 && my_queries) atomicAdd(&C->queries, my_queries);
