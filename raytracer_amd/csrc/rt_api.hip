@@ -852,6 +852,19 @@ static int drain(rt_scene* s) {
     }
 #endif
 #ifdef RT_DEBUG_KERNEL
+    if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 26))) {
+      unsigned long long w[12] = {0}, z[12] = {0};
+      hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_fast_cyc), sizeof w);
+      hipMemcpyToSymbol(HIP_SYMBOL(rt::g_fast_cyc), z, sizeof z);
+      if (w[10]) {
+        const double a = (double)w[10];
+        fprintf(stderr, "[rt debug] k_shade_fast wave cycles: per-hit set-up %.3f, light set-up %.3f, wave-level lists %.3f, sample directions %.3f, planes %.3f, "
+                "hierarchy phases + sample blocks %.3f, deferred fp64 decisions %.3f, merged-crossing check %.3f, Phong + re-test queue %.3f, accumulate + spawn + grab %.3f of %llu\n",
+                w[0] / a, w[1] / a, w[2] / a, w[3] / a, w[4] / a, w[5] / a, w[6] / a, w[7] / a, w[8] / a, w[9] / a, w[10]);
+      }
+    }
+#endif
+#ifdef RT_DEBUG_KERNEL
     if (pf.precision == RT_FP32 && getenv("RT_DEBUG_STATS") && (atoi(getenv("RT_DEBUG_STATS")) & (1 << 25))) {
       unsigned long long w[8] = {0}, z[8] = {0};
       hipMemcpyFromSymbol(w, HIP_SYMBOL(rt::g_walk_audit), sizeof w);

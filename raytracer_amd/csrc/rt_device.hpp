@@ -440,6 +440,7 @@ __device__ unsigned long long g_walk_dbg[8];
 __device__ unsigned long long g_forced_cause[8]; // ... and which special case forced it (RT_UNC_FORCED tags)
 __device__ unsigned long long g_walk_audit[8];   // audit build, bit 25: [0] pairs k_shade_ls / k_shade_fast decided themselves and checked, [1] of them wrong
 __device__ unsigned long long g_fix_cause[8];    // k_shade_ls: why (hit, light) pairs went to the re-test queue (RT_DEBUG_STATS bit 23)
+__device__ unsigned long long g_fast_cyc[12];    // k_shade_fast wave cycles by section (RT_DEBUG_STATS bit 26), see FCK in rt_shade_fast.hpp
 __device__ unsigned long long g_pool_cyc[8];     // k_trace_pool wave cycles: refill, node steps, leaf bounds, exact tests, results, all, rounds
 __device__ __forceinline__ bool wave_first_active() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
 #ifdef RT_NO_WALK_COUNT     // (cycle profiles: the counting atomics would dominate)

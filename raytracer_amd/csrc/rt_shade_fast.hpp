@@ -134,12 +134,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
   const int n_cells = n_sh > 1 ? n_sh * n_sh : 1;
   const float inv_cells = 1.0f / (float)n_cells;
   const long long ck_kernel = (RT_DBG(fp) & 2048u) ? clock64() : 0;
+  // audit build, RT_DEBUG_STATS bit 26: wave cycles by section of the kernel -> g_fast_cyc (0 per-hit set-up, 1 light set-up,
+  // 2 wave-level lists, 3 sample directions, 4 planes, 5 hierarchy phases + sample blocks, 6 deferred fp64 decisions,
+  // 7 merged-crossing check, 8 Phong + re-test queue, 9 accumulate + spawn + chunk grab, 10 all)
+#ifdef RT_DEBUG_KERNEL
+  const bool fprof = (RT_DBG(fp) & (1u << 26)) != 0u;
+  long long fck0 = 0, fck1 = 0, fck2 = 0, fck3 = 0, fck4 = 0, fck5 = 0, fck6 = 0, fck7 = 0, fck8 = 0, fck9 = 0;
+  long long fck_t = fprof ? clock64() : 0;
+  const long long fck_begin = fck_t;
+#define FCK(v) do { if (fprof) { const long long t__ = clock64(); v += t__ - fck_t; fck_t = t__; } } while (0)
+#else
+#define FCK(v) do { } while (0)
+#endif
   for (;;) {
     uint32_t base = grab64(&C->work_shade[level]);
     if (base >= count) {
       if ((RT_DBG(fp) & 2048u) && lane == 0) atomicAdd(&C->dbg[0], (unsigned long long)(clock64() - ck_kernel));
       break;
     }
+    FCK(fck9);
     uint32_t h = base + lane;
     bool active = h < count;
     RayIn r; d3 hp = mk3(0, 0, 0), n = mk3(0, 0, 0);
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         for (int o_ = 32; o_ > 0; o_ >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o_));
         rho = raw_sqrt(r2) * 1.0001f;
       }
+      FCK(fck0);
       for (int li = 0; li < sc.nL; ++li) {
         const double* lg = sc.lights + LIGHT_STRIDE * li;
         const f3 tl = mkf((float)(lg[0] - p.x), (float)(lg[1] - p.y), (float)(lg[2] - p.z));
@@ -223,6 +237,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         }
         if (skip_samples) total = lane_dark ? 0.0f : (float)n_cells;        // n^2 terms of exactly 0 or 1
         int n_wl = -1, n_wr = -1;
+        FCK(fck1);
         if (coop) {
           // segment cw -> Lp against the node box grown by max(rho, RL) (+ fp32 slack), 0 <= tau <= 1
           const f3 tw = mkf((float)lg[0] - cw.x, (float)lg[1] - cw.y, (float)lg[2] - cw.z);
@@ -287,6 +302,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             atomicAdd(&C->dbg[3], (unsigned long long)(n_wr < 0 ? 0 : n_wr));
           }
         }
+        FCK(fck2);
         for (int c = 0; c < (skip_samples ? 0 : n_chunks); ++c) {
           float dx[CH], dy[CH], dz[CH], md[CH], tr[CH];
           // inverse directions for the box slabs: kept per sample for LDS scenes; the large-scene kernel
@@ -311,6 +327,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             tr[s] = (cellidx < n_cells) ? 1.0f : 0.0f;
             if (KEEP_INV) { ix[s] = raw_rcp(dx[s]); iy[s] = raw_rcp(dy[s]); iz[s] = raw_rcp(dz[s]); }
           }
+          FCK(fck3);
           // one primitive's crossings folded into a sample's transmission product
           auto apply = [&](float& t_, bool in1, bool in2, float tau) __attribute__((always_inline)) {
             if (OPAQUE) { t_ = (in1 | in2) ? 0.0f : t_; }
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             }
             retest(k, fmask);
           }
+          FCK(fck4);
           if (!LDS_SCENE && ac.n_nodes > 0 && !fp.brute) {
             // Large scene: each lane walks the culling hierarchy with the hull of ITS shadow segments
             // to this light (all samples lie within RL of the light centre) and runs the sample block
@@ -682,6 +700,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               for (int k = sc.nS + sc.nP, e = sc.n; k < e; ++k)
                 if (cand.has(k)) do_box(P[k], k);
           }
+          FCK(fck5);
           while (__any(dm0 != 0u)) {                         // the deferred exact decisions of this chunk, one sample per turn
             bool e1 = false, e2 = false;
             float tau = 0.0f;
@@ -698,6 +717,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             dm0 &= dm0 - 1u;
             if (dm0 == 0u) { dk0 = dk1; dm0 = dm1; dk1 = -1; dm1 = 0u; }
           }
+          FCK(fck6);
           if (!OPAQUE && ncross > WALK_CAP && !fp.sequential) unc = 1.0f;   // a sample may cross more surfaces than the walk visits
 #pragma unroll
           for (int s = 0; s < CH; ++s) total += tr[s];
@@ -732,6 +752,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               if (close) unc = 1.0f;
             }
           }
+          FCK(fck7);
         }
         if ((RT_DBG(fp) & 2u) && LDS_SCENE && active) {      // audit build, shortcut disabled: check what it would have claimed
           if (lane_lit && total != (float)n_cells) atomicAdd(&C->dbg[0], 1ull);
@@ -789,6 +810,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
                     (float)r.w.y * cm * (float)lg[4] * fmaf((float)mat[1], ndl, (float)mat[4] * sp),
                     (float)r.w.z * cm * (float)lg[5] * fmaf((float)mat[2], ndl, (float)mat[5] * sp), r.lp, gpix, level, li);
         }
+        FCK(fck8);
       }
       const float one_m = 1.0f - (float)mat[10];
       float bt[3] = {0.0f, 0.0f, 0.0f};
@@ -801,6 +823,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
     }
     spawn_children(active, level, fp, mat, r, hp, n, nq, C, spawn_segment(base >> 6, count));
   }
+#ifdef RT_DEBUG_KERNEL
+  if (fprof && lane == 0) {
+    const long long v_[10] = {fck0, fck1, fck2, fck3, fck4, fck5, fck6, fck7, fck8, fck9};
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_fast_cyc[i], (unsigned long long)v_[i]);
+    atomicAdd(&g_fast_cyc[10], (unsigned long long)(clock64() - fck_begin));
+  }
+#endif
+#undef FCK
 }
 
 #ifndef RT_NO_LAUNCHERS   // (single-kernel compile harness: tools/one_kernel.sh)

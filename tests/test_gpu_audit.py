@@ -23,7 +23,7 @@ def test_shortcut_claims_agree_with_the_sample_loop():
     if not os.path.exists(DEBUG_LIB):
         pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
     env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS="2")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "pool4k", "--frames", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "pool4k", "--frames", "1", "--host-out"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     found = re.findall(r"fully-lit claims wrong (\d+), umbra claims wrong (\d+), penumbra lanes (\d+) of (\d+)", p.stderr)
@@ -48,7 +48,7 @@ def test_large_scene_culling_never_drops_a_crossed_record():
     if not os.path.exists(DEBUG_LIB):
         pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
     env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS="65536")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "synth4k", "--scale", "4", "--frames", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "synth4k", "--scale", "4", "--frames", "1", "--host-out"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     crossings, dropped, frames = _audit_counts(p.stderr)
@@ -73,7 +73,7 @@ def test_fp32_decided_pairs_agree_with_the_exact_walk():
         pytest.fail("librt_hip_debug.so is missing: run __graft_entry__.build() (make -C raytracer_amd/csrc debug)")
     env = dict(os.environ, RT_HIP_LIBRARY=DEBUG_LIB, RT_DEBUG_STATS=str(1 << 25))
     # the headline kernel on the headline scene (1920x1080; the full 4K frame by hand: 54,853,298 pairs, 0 differ)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "pool4k", "--scale", "2", "--frames", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "quick_bench.py"), "pool4k", "--scale", "2", "--frames", "1", "--host-out"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     found = re.findall(r"walk audit: (\d+) \(hit, light\) pairs decided in fp32 checked against the exact walk, (\d+) differ", p.stderr)
