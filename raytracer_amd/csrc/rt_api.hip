@@ -1067,7 +1067,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
   for (int level = 0; level <= fp.max_depth; ++level) {
     RayQueue cur = q[level & 1], nxt = q[(level + 1) & 1];
     int tgrid = grid;       // trace: one workgroup per TRACE_CHUNK rays, grid-stride beyond that
-    int sgrid = grid;       // shade
+    int sgrid = grid;       // shade: an upper bound, the launchers cut it to the resident workgroups (shade_grid)
     if (level == 0) {
       tgrid = (int)std::min<size_t>((size_t)grid * 4, ((size_t)P + TRACE_CHUNK - 1) / TRACE_CHUNK);
       sgrid = (int)std::min<size_t>((size_t)grid, ((size_t)P + BLOCK - 1) / BLOCK);
@@ -1097,15 +1097,15 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
       if (fr->precision == RT_FP64) {
         // LDS-resident scenes: the shadow samples of the penumbra lanes spread over the wave (k_shade_exact_items); RT_EXACT_ITEMS=0: one lane per hit (A/B)
         if (items_kernel)
-          hipLaunchKernelGGL((k_shade_exact_items<FB>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
-        else if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
-        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(sgrid), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+          hipLaunchKernelGGL((k_shade_exact_items<FB>), dim3(shade_grid<k_shade_exact_items<FB>>(s->num_cu, sgrid)), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+        else if (lds) hipLaunchKernelGGL((k_shade_exact<FB, true>), dim3(shade_grid<k_shade_exact<FB, true>>(s->num_cu, sgrid)), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
+        else hipLaunchKernelGGL((k_shade_exact<FB, false>), dim3(shade_grid<k_shade_exact<FB, false>>(s->num_cu, sgrid)), dim3(BLOCK), 0, s->stream, s->ds, cam, fp, level, cur, nxt, level_hits, wb.counters, fb);
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0 && s->n_coincident == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
+        if (s->shade_variant == 0 && s->n_coincident == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->num_cu, s->stream);
         if (!done)
-          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->stream);
+          launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->num_cu, s->stream);
       }
     }
   }

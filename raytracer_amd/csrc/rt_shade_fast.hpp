@@ -845,10 +845,10 @@ static inline int pick_chunk(int n_cells) {
 template <int CH>
 static void launch_shade_fast_ch(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
                                  RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
-                                 hipStream_t st, int n_chunks) {
+                                 int num_cu, hipStream_t st, int n_chunks) {
   const bool lds = ds.n <= LDS_PRIMS, box = ds.nB > 0;
 #define RT_LAUNCH(OP, BX, LD)                                                                                     \
-  hipLaunchKernelGGL((k_shade_fast<CH, OP, BX, LD>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, \
+  hipLaunchKernelGGL((k_shade_fast<CH, OP, BX, LD>), dim3(shade_grid<k_shade_fast<CH, OP, BX, LD>>(num_cu, grid)), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, \
                      hits, C, fb, n_chunks, fix)
   if (opaque) {
     if (!box && lds) RT_LAUNCH(true, false, true);
@@ -864,14 +864,14 @@ static void launch_shade_fast_ch(const DevScene& ds, bool opaque, const DevCamer
 
 static void launch_shade_fast(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
                               RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
-                              hipStream_t st) {
+                              int num_cu, hipStream_t st) {
   const int n_cells = fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1;
   const int ch = pick_chunk(n_cells);
   const int n_chunks = (n_cells + ch - 1) / ch;
   switch (ch) {
-    case 9: launch_shade_fast_ch<9>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
-    case 4: launch_shade_fast_ch<4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
-    default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, st, n_chunks); break;
+    case 9: launch_shade_fast_ch<9>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, num_cu, st, n_chunks); break;
+    case 4: launch_shade_fast_ch<4>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, num_cu, st, n_chunks); break;
+    default: launch_shade_fast_ch<1>(ds, opaque, cam, fp, level, cur, nxt, hits, C, fb, fix, grid, num_cu, st, n_chunks); break;
   }
 }
 

@@ -1326,10 +1326,10 @@ static bool shade_ls_serves(const DevScene& ds, const FrameParams& fp) {
 
 static bool launch_shade_ls(const DevScene& ds, bool opaque, const DevCamera& cam, const FrameParams& fp, int level,
                             RayQueue cur, RayQueue nxt, const HitRec* hits, Counters* C, float* fb, FixRec* fix, int grid,
-                            hipStream_t st) {
+                            int num_cu, hipStream_t st) {
   if (!shade_ls_serves(ds, fp)) return false;
 #define RT_LS_K(S, Pn, B, O, F)                                                                                       \
-  hipLaunchKernelGGL((k_shade_ls<S, Pn, B, O, F>), dim3(grid), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, hits, C, fb, fix)
+  hipLaunchKernelGGL((k_shade_ls<S, Pn, B, O, F>), dim3(shade_grid<k_shade_ls<S, Pn, B, O, F>>(num_cu, grid)), dim3(BLOCK), 0, st, ds, cam, fp, level, cur, nxt, hits, C, fb, fix)
   // fused frames (fp.fuse0 == 2): one instantiation for level 0 (camera rays, no queue input) and one for the levels that
   // read the HitRay queue — neither carries the other's arguments and code
 #define RT_LS(S, Pn, B)                                                                                             \
