@@ -801,14 +801,21 @@ __device__ __forceinline__ double shadow_walk(const Prim* __restrict__ P, int nS
 // The fp32 slack (1e-5 relative to the magnitudes involved) exceeds the rounding of this arithmetic by
 // two orders of magnitude; far hits, where |oc|^2 ~ |tl|^2 >> r^2, never get a lane_full claim.
 struct FanCull { PrimMask act; bool lane_can, lane_full; };
-__device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __restrict__ P, d3 p, d3 Lp, float RLin) {
-  FanCull fc; fc.act.lo = fc.act.hi = 0ull; fc.lane_can = false; fc.lane_full = false;
-  const float RL = RLin * 1.001f;
-  const float tx = (float)(Lp.x - p.x), ty = (float)(Lp.y - p.y), tz = (float)(Lp.z - p.z);
-  const float T0 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-  const float qa = T0 - RL * RL, rqa = 1.0f / qa, rT0 = 1.0f / T0;
-  int k = 0;
-  for (int e = sc.nS; k < e; ++k) {
+struct FanTerms { float tx, ty, tz, T0, qa, rqa, rT0, RL; };       // per (hit, light)
+__device__ __forceinline__ FanTerms fan_terms(d3 p, d3 Lp, float RLin) {
+  FanTerms f;
+  f.RL = RLin * 1.001f;
+  f.tx = (float)(Lp.x - p.x); f.ty = (float)(Lp.y - p.y); f.tz = (float)(Lp.z - p.z);
+  f.T0 = fmaf(f.tz, f.tz, fmaf(f.ty, f.ty, f.tx * f.tx));
+  f.qa = f.T0 - f.RL * f.RL; f.rqa = 1.0f / f.qa; f.rT0 = 1.0f / f.T0;
+  return f;
+}
+// One primitive against the fan of one (hit, light): can = it may cross some shadow segment, full = (spheres of all-opaque
+// scenes) it swallows the whole fan.
+__device__ __forceinline__ void fan_test_prim(const DevScene& sc, const Prim* __restrict__ P, d3 p, const FanTerms& f, int k, bool& can, bool& full) {
+  const float tx = f.tx, ty = f.ty, tz = f.tz, T0 = f.T0, qa = f.qa, rqa = f.rqa, rT0 = f.rT0, RL = f.RL;
+  full = false;
+  if (k < sc.nS) {
     const Prim& s = P[k];
     const double ox = p.x - s.a[0], oy = p.y - s.a[1], oz = p.z - s.a[2];
     const float cc = (float)(((ox * ox + oy * oy) + oz * oz) - s.a[4]);    // epsilon-carrying term from fp64
@@ -820,30 +827,23 @@ __device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __re
     // every segment direction leaves the sphere: oc.ts >= A - RL*|oc| > 0 with the origin outside
     const float ocn = sqrtf(fmaxf(cc + r2, 0.0f));
     const bool away = (cc >= 0.0f) & (A - RL * ocn > 1e-5f * (fabsf(A) + ocn * sqrtf(T0) + 1e-3f));
-    const bool can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc) + r2))) & !away;
-    fc.lane_can |= can;
-    if (__any(can)) fc.act.set(k);
+    can = ((qa <= 0.0f) | (g <= 1e-5f * (T0 + fabsf(cc) + r2))) & !away;
     if (sc.all_opaque) {
       const float ts = fminf(fmaxf(-A * rT0, 0.0f), 1.0f);
       const float dist2 = fmaf(ts, fmaf(ts, T0, 2.0f * A), cc + r2);       // |oc + ts*tl|^2
       const float room = r * 0.999f - ts * RL;
       const float lend2 = (cc + r2) + 2.0f * A + T0;                       // |oc + tl|^2: light centre to sphere centre
       const bool trust = (fabsf(cc) < 1000.0f * r2) & (T0 < 1000.0f * r2) & (r > 0.1f);
-      fc.lane_full |= trust & (cc > 0.0f) & (room > 0.0f) & (dist2 < room * room) &
-                      (lend2 > (r + RL) * (r + RL) * 1.01f);
+      full = trust & (cc > 0.0f) & (room > 0.0f) & (dist2 < room * room) & (lend2 > (r + RL) * (r + RL) * 1.01f);
     }
-  }
-  for (int e = sc.nS + sc.nP; k < e; ++k) {
+  } else if (k < sc.nS + sc.nP) {
     const Prim& s = P[k];
     const float num = (float)(s.a[3] - ((p.x * s.a[0] + p.y * s.a[1]) + p.z * s.a[2]));
     const float D0 = fmaf((float)s.a[2], tz, fmaf((float)s.a[1], ty, (float)s.a[0] * tx));   // N.tl, |N| = 1
     const float spread = RL * 1.001f + 1e-5f * (fabsf(D0) + sqrtf(T0));
     // tau = num / (N.ts) in (0, 1) needs num and N.ts of the same sign; N.ts is within `spread` of D0
-    const bool can = num < 0.0f ? (D0 - spread <= 0.0f) : (num > 0.0f ? (D0 + spread >= 0.0f) : true);
-    fc.lane_can |= can;
-    if (__any(can)) fc.act.set(k);
-  }
-  for (int e = sc.n; k < e; ++k) {               // boxes: hull against the bounding sphere (centre, half diagonal)
+    can = num < 0.0f ? (D0 - spread <= 0.0f) : (num > 0.0f ? (D0 + spread >= 0.0f) : true);
+  } else {                                       // boxes: hull against the bounding sphere (centre, half diagonal)
     const Prim& b = P[k];
     const float cx = (float)(0.5 * (b.a[0] + b.a[3]) - p.x), cy = (float)(0.5 * (b.a[1] + b.a[4]) - p.y),
                 cz = (float)(0.5 * (b.a[2] + b.a[5]) - p.z);                                  // box centre - p = -oc
@@ -854,11 +854,43 @@ __device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __re
     const float qb = A - r * RL;
     const float tau = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);
     const float g = fmaf(tau, fmaf(tau, qa, 2.0f * qb), oc2 - r * r);
-    const bool can = (qa <= 0.0f) | (g <= 1e-5f * (T0 + oc2 + r * r));
-    fc.lane_can |= can;
+    can = (qa <= 0.0f) | (g <= 1e-5f * (T0 + oc2 + r * r));
+  }
+}
+__device__ __forceinline__ FanCull fan_cull(const DevScene& sc, const Prim* __restrict__ P, d3 p, d3 Lp, float RLin) {
+  FanCull fc; fc.act.lo = fc.act.hi = 0ull; fc.lane_can = false; fc.lane_full = false;
+  const FanTerms f = fan_terms(p, Lp, RLin);
+  for (int k = 0; k < sc.n; ++k) {               // (k is wave-uniform: the type branches of fan_test_prim are scalar)
+    bool can, full;
+    fan_test_prim(sc, P, p, f, k, can, full);
+    fc.lane_can |= can; fc.lane_full |= full;
     if (__any(can)) fc.act.set(k);
   }
-  if (!(T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; fc.act.lo = fc.act.hi = ~0ull; }   // light at the hit point
+  if (!(f.T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; fc.act.lo = fc.act.hi = ~0ull; }   // light at the hit point
+  return fc;
+}
+// The same for a wave whose lanes form GROUPS of g lanes (a power of two) that hold copies of one (hit, light) each
+// (k_fix_exact: one shadow sample per lane): the group's lanes share the primitives out — lane `member` tests primitives
+// member, member + g, ... — instead of every lane testing all of them.  Same tests, same results: act is the union over
+// the wave's records, the claims are per record.  All 64 lanes must call it.
+__device__ __forceinline__ FanCull fan_cull_group(const DevScene& sc, const Prim* __restrict__ P, d3 p, d3 Lp, float RLin, uint32_t member, int g) {
+  FanCull fc; fc.act.lo = fc.act.hi = 0ull; fc.lane_can = false; fc.lane_full = false;
+  const FanTerms f = fan_terms(p, Lp, RLin);
+  const uint32_t gbase = __lane_id() - member;                                  // first lane of this lane's group
+  const unsigned long long ones = g >= 64 ? ~0ull : ((1ull << g) - 1ull);
+  const unsigned long long gmask = ones << gbase;
+  const unsigned long long every_g = g >= 64 ? 1ull : ~0ull / ones;             // bit 0 of every group
+  for (int k0 = 0; k0 < sc.n; k0 += g) {
+    const int k = k0 + (int)member;
+    bool can = false, full = false;
+    if (k < sc.n) fan_test_prim(sc, P, p, f, k, can, full);
+    const unsigned long long mc = __ballot(can), mf = __ballot(full);
+    fc.lane_can |= (mc & gmask) != 0ull; fc.lane_full |= (mf & gmask) != 0ull;
+    for (int j = 0; j < g && k0 + j < sc.n; ++j)                                // primitive k0 + j: the lanes with member == j
+      if (mc & (every_g << j)) fc.act.set(k0 + j);
+  }
+  if (!(f.T0 > 1e-6f)) { fc.lane_can = true; fc.lane_full = false; }           // light at the hit point
+  if (__any(!(f.T0 > 1e-6f))) fc.act.lo = fc.act.hi = ~0ull;
   return fc;
 }
 

@@ -1147,7 +1147,8 @@ __global__ __launch_bounds__(BLOCK) void k_fix_exact(DevScene sc, FrameParams fp
     PrimMask cmask = PrimMask::all();
     bool claim = false; double claimed = 0.0;
     if (LDS_SCENE) {
-      const FanCull fc = fan_cull(sc, P, p, mk3(lg[0], lg[1], lg[2]), fp.n_shadow > 1 ? 0.7072f * (float)lg[8] : 0.0f);
+      // (the g lanes of a record share its primitives out: fan_cull_group)
+      const FanCull fc = fan_cull_group(sc, P, p, mk3(lg[0], lg[1], lg[2]), fp.n_shadow > 1 ? 0.7072f * (float)lg[8] : 0.0f, member, g);
       cmask = fc.act;
       if (!fc.lane_can) { claim = true; claimed = 1.0; }
       else if (fc.lane_full) { claim = true; claimed = 0.0; }
