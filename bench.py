@@ -7,11 +7,16 @@
 A step = one frame: every rank renders its interleaved row blocks of the frame into device memory
 (the scene is already resident in HBM) and, for N > 1, the tiles are gathered to rank 0 over RCCL.
 The frame is fixed as N grows (strong scaling).  Rank 0 prints ONE JSON line.
+For every N two frames are in flight on each rank (two scene handles on two non-blocking streams: the next frame's
+level 0 fills the tails of this frame's small launches; for N > 1 the gather of frame k also overlaps the render of
+k + 1), so `value` / `ms_per_step` are throughput numbers; `one_frame_at_a_time` (N = 1) carries the frame time of the
+same frames rendered one after the other on one stream, and RT_BENCH_PIPELINE=0 makes that the headline.
 
 metric/value: Mrays/s, rays = radiance rays + shadow rays of the frame, whole job.
 roofline: the dominant kernel (k_shade_ls / k_shade_fast / k_shade_exact) — algorithmic flops of its launches
   (raytracer_amd/flops.py) / their summed duration, measured with HIP events on the
-  stream the kernels run on (rt_stats, RT_FLAG_TIMING) on every --timing-every-th frame of the timed steps.  The bound is the
+  stream the kernels run on (rt_stats, RT_FLAG_TIMING) on every --timing-every-th frame (N = 1: of the serial loop, so that
+  overlap does not distort them).  The bound is the
   vector ALU (no MFMA-shaped work, HBM traffic is one framebuffer write), peak = 157.3 TFLOP/s fp32
   / 78.6 fp64 (MI355X_MICROARCH.md chip table).
 cpu_baseline: the C oracle (oracle/rt_oracle.c, a port of the reference's algorithm) timed on this
@@ -179,7 +184,7 @@ def main():
     # workspace, render stream and tile buffer), so the kernels of frame k+1 fill the tails of frame k's
     # small launches, and the gather of frame k (comm stream) overlaps the render of frame k+1.
     # RT_BENCH_PIPELINE=0 serialises everything on one stream (frame latency).
-    pipelined = world > 1 and os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
+    pipelined = os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
     n_buf = 2 if pipelined else 1
     tiles = [torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev) for _ in range(n_buf)]
     tile = tiles[0]
@@ -188,9 +193,13 @@ def main():
     every = max(1, args.timing_every)
 
     def flags_of(k):
+        if world == 1 and pipelined:      # (N = 1: the event-timed frames come from a serial loop after the timed region)
+            return _lib.RT_FLAG_ASYNC
         return _lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0)
     scenes = [gs]
-    if pipelined:
+    if pipelined and world == 1:
+        scenes.append(GpuScene(packed, device=local_rank))      # (each handle renders on its own private non-blocking stream)
+    elif pipelined:
         scenes.append(GpuScene(packed, device=local_rank))
         render_streams = [new_stream(dev), new_stream(dev)]
         comm_stream = new_stream(dev)
@@ -225,6 +234,10 @@ def main():
                     timed_gather(serial_stream, k, tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             return
         b = k & 1
+        if world == 1:
+            scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                             out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
+            return
         render_stream = render_streams[b]
         if tile_free[b] is not None:
             render_stream.wait_event(tile_free[b])          # the gather of frame k-2 has read this tile
@@ -261,6 +274,23 @@ def main():
     elapsed = time.perf_counter() - t0
     for sc_ in scenes:
         sc_.sync()   # folds counters / event timings into the rt_stats of the timed steps
+    # N = 1 with two frames in flight: the same K frames once more, one after the other on ONE stream — the frame time
+    # comparable with rounds 1-2, and the event-timed kernel durations of the roofline block (not distorted by overlap)
+    timed_source, serial = all_stats, None
+    if world == 1 and pipelined:
+        ser_stats = [_lib.Stats() for _ in range(args.steps)]
+        for _ in range(3):
+            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                      out_ptr=tile.data_ptr(), flags=_lib.RT_FLAG_ASYNC)
+        gs.sync(); torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for k, s_ in enumerate(ser_stats):
+            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows, out_ptr=tile.data_ptr(),
+                      flags=_lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0), stats=s_)
+        torch.cuda.synchronize()
+        serial = (time.perf_counter() - ts) / args.steps * 1e3
+        gs.sync()
+        timed_source = ser_stats
 
     # whole-job numbers: max time over ranks, rays summed over ranks
     last = all_stats[-1]
@@ -306,10 +336,10 @@ def main():
         value = total_rays / (ms_per_step * 1e-3) / 1e6
         n_sph, n_pln, n_box = packed.counts
         # dominant kernel on this rank: shade launches of the timed steps
-        timed = [s for k, s in enumerate(all_stats) if k % every == 0] if not args.no_timing else []
+        timed = [s for k, s in enumerate(timed_source) if k % every == 0] if not args.no_timing else []
         shade_ms = sum(s.shade_ms for s in timed) / max(len(timed), 1)     # frames bracketed with HIP events
         trace_ms = sum(s.trace_ms for s in timed) / max(len(timed), 1)
-        launches = max(all_stats[0].shade_launches, 1)
+        launches = max(timed_source[0].shade_launches, 1)
         seg = max(int(last.segments), 0)
         # (frames whose shade kernel traces its own rays — k_shade_ls, fused — execute those queries in the timed launches too)
         fused_rays, fused_children = rays_traced_by_shade_kernel(timed[0].as_dict()) if timed else (0, 0)
@@ -413,7 +443,8 @@ def main():
             "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
                        "shadow_rays": int(shadow), "row_blocks": args.block_rows,
                        "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")
-                                      + (", 2 frames in flight (two streams; gather k overlaps render k+1)" if pipelined else "")},
+                                      + (", 2 frames in flight (two streams; gather k overlaps render k+1)" if (pipelined and world > 1) else "")
+                                      + (", 2 frames in flight (two scene handles, two streams)" if (pipelined and world == 1) else "")},
             "roofline": roofline,
         }
         if world > 1 and roofline is not None:
@@ -423,7 +454,12 @@ def main():
             out["verify"] = verify
         if multi is not None:
             out["multi"] = multi
-        if world == 1:
+        if serial is not None:
+            out["one_frame_at_a_time"] = {"ms_per_step": round(serial, 4), "value": round(total_rays / (serial * 1e-3) / 1e6, 2), "unit": "Mrays/s",
+                                          "steps": args.steps,
+                                          "note": "the same frames one after the other on one stream (RT_BENCH_PIPELINE=0 makes this the headline): "
+                                                  "frame time as measured in rounds 1-2; roofline.culled comes from these frames' HIP events"}
+        if world == 1 and not pipelined:
             # Throughput with TWO frames in flight (two scene handles on two streams, as the N > 1 runs do): the next frame's
             # level 0 fills the tails of this frame's small launches.  Reported beside the headline, which stays one frame
             # after the other on one stream (`value`, `ms_per_step`).  Outside the timed region.
