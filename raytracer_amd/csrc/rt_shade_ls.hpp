@@ -39,6 +39,12 @@
 //    shaded with T = 0 and queued (FixRec); k_fix_exact adds its exact fp64 shadow term afterwards.
 //    north_star: "fp32 fast mode within <= 1/255 per 8-bit channel" — met on every channel, because no
 //    shadow sample can flip (tests/test_gpu_parity.py gates on the maximum, not on a fraction).
+//  * (round 3) All-opaque scenes whose candidate spheres have the shadow origin outside them use a loop WITHOUT square
+//    roots or reciprocals (ls_light_sum_simple): blocked <=> min3(disc, -oc.ts, oc.ts + |ts|^2) > 0, counted with the
+//    clamp bit of a packed multiply; the bit-pattern form above serves scenes with transparency and the LO path.
+//  * (round 3) Fused frames (FrameParams::fuse0 == 2, template parameter FALL): the kernel forms the camera ray of its
+//    pixel at level 0, traces the children its hits spawn and hands the children's HITS on as 64-byte HitRay records —
+//    one launch per level, no k_trace (see the kernel's comments and DESIGN.md section 3).
 #pragma once
 #include "rt_kernels.hpp"
 #include "rt_shade_fast.hpp"
