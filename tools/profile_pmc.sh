@@ -17,4 +17,6 @@ run() {  # name, counters...
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY &&
 run sq2 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_THREAD_CYCLES_VALU &&
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE &&
-run write WRITE_SIZE GRBM_COUNT
+run write WRITE_SIZE GRBM_COUNT &&
+# LDS: instructions, busy and stalled cycles (bank conflicts of the scene staging / the kernels' LDS tables)
+run lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS
