@@ -101,3 +101,53 @@ def test_a_failing_handle_leaves_the_others_usable(monkeypatch):
     finally:
         for gs in scenes:
             gs.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp64"])
+def test_two_frames_in_flight_give_the_single_frames(oracle, precision):
+    """bench.py's throughput mode: frames alternate between two scene handles (own streams, own workspaces) with
+    RT_FLAG_ASYNC, so that the kernels of two frames share the GPU.  Every frame must be the frame a blocking call on one
+    handle renders (different jitter seeds per frame, so a mixed-up workspace would show), and match the oracle."""
+    from raytracer_amd import _lib, load_scene
+    from raytracer_amd.packing import pack_scene
+    from raytracer_amd.render import GpuScene
+    W, H, n, depth = 384, 216, 3, 3
+    cam, st, mats, surfs, lights = load_scene(scene_path("pool.txt" if precision == "fp32" else "original.txt"), n, depth)
+    cam.setup(W / H)
+    packed = pack_scene(mats, surfs, lights, st.background_color)
+    item = 4 if precision == "fp32" else 8
+    dt = np.float32 if precision == "fp32" else np.float64
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_frames = 6
+    bufs = []
+    for _ in range(n_frames):
+        b = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(b), W * H * 3 * item) == 0
+        bufs.append(b)
+    a, b2 = GpuScene(packed), GpuScene(packed)
+    try:
+        stats = [_lib.Stats() for _ in range(n_frames)]
+        for k in range(n_frames):
+            (a if k % 2 == 0 else b2).render(cam, W, H, n, depth, precision=precision, jitter=100 + k, out_ptr=bufs[k].value,
+                                             flags=_lib.RT_FLAG_ASYNC, stats=stats[k])
+        a.sync(); b2.sync()
+        for k in range(n_frames):
+            got = np.empty((H, W, 3), dtype=dt)
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), bufs[k], got.nbytes, 2) == 0
+            single = a.render(cam, W, H, n, depth, precision=precision, jitter=100 + k)
+            s1 = dict(a.last_stats)
+            assert int(stats[k].rays) == s1["rays"] and int(stats[k].hits) == s1["hits"] and int(stats[k].shadow_rays) == s1["shadow_rays"]
+            if precision == "fp64":
+                assert rel_err(got, single).max() < 1e-12
+            else:
+                assert np.abs(got.astype(np.float64) - single.astype(np.float64)).max() < 1e-5      # (float atomics' order)
+            if k < 2:
+                ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 100 + k))
+                if precision == "fp64":
+                    assert rel_err(got, ref).max() < 1e-9
+                else:
+                    assert np.abs(_q(got) - _q(ref)).max() <= 1
+    finally:
+        a.close(); b2.close()
+        for b in bufs:
+            hip.hipFree(b)
