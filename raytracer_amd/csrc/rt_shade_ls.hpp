@@ -797,22 +797,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
     uint32_t bad_cc = 0u;                         // spheres the shadow origin is inside of, or whose surface it lies on without being the hit's own (ls_light_sum_simple's precondition)
     float a_sgn[MAXS];
+    // (LDS reads one slot ahead, here and in the light loop: with two waves per SIMD a read + wait per slot stalls the wave
+    // for the LDS latency each time; the record array has MAXS + MAXP + MAXB entries, so slot k + 1 always exists)
+    double pc0 = P[0].a[0], pc1 = P[0].a[1], pc2 = P[0].a[2], pc4 = P[0].a[4];
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
       a_Cc[k] = mk2(0.0f, 1.0f); a_sgn[k] = -1.0f; a_AB[k] = mk2(0.0f, 0.0f);
+      const double c0_ = pc0, c1_ = pc1, c2_ = pc2, r2_ = pc4;
+      if (k + 1 < MAXS) { pc0 = P[k + 1].a[0]; pc1 = P[k + 1].a[1]; pc2 = P[k + 1].a[2]; pc4 = P[k + 1].a[4]; }
       if (k < nS) {
         const Prim& s_ = P[k];
-        const double ox = p.x - s_.a[0], oy = p.y - s_.a[1], oz = p.z - s_.a[2];
-        const float cc = (float)(((ox * ox + oy * oy) + oz * oz) - s_.a[4]);
+        const double ox = p.x - c0_, oy = p.y - c1_, oz = p.z - c2_;
+        const float cc = (float)(((ox * ox + oy * oy) + oz * oz) - r2_);
         a_Cc[k].y = cc;
         // far root iff the origin is inside — and for the hit's OWN sphere seen from outside: the near root of a ray that
         // re-enters it is the crossing at the shadow origin itself (t' = 1e-6/cos, which the reference may or may not
         // see); the far root decides, as in the reference, unless the light is inside the sphere (LO path)
         a_sgn[k] = (cc < 0.0f || own == k) ? 1.0f : -1.0f;
-        near_scene &= fabsf(cc) < 1000.0f * (float)s_.a[4];
-        oc2max = fmaxf(oc2max, cc + (float)s_.a[4]);
+        near_scene &= fabsf(cc) < 1000.0f * (float)r2_;
+        oc2max = fmaxf(oc2max, cc + (float)r2_);
         if (own == k) { own_in_bit = cc < 0.0f ? 1u << k : 0u; own_out_bit = cc < 0.0f ? 0u : 1u << k; }
-        bad_cc |= ((cc < 0.0f) | ((own != k) & (cc < 1e-4f * (float)s_.a[4]))) ? 1u << k : 0u;
+        bad_cc |= ((cc < 0.0f) | ((own != k) & (cc < 1e-4f * (float)r2_))) ? 1u << k : 0u;
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -891,13 +896,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     if (prof) { const long long t = clock64(); ck_hit += t - ck_t; ck_t = t; }
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
+    // (the next light's position is read from LDS while this light's Phong terms are formed, see the end of the loop body)
+    float nlx = s_lightf[0][0], nly = s_lightf[0][1], nlz = s_lightf[0][2], nmx = s_lightl[0][0], nmy = s_lightl[0][1], nmz = s_lightl[0][2];
     for (int li = 0; li < sc.nL; ++li) {
       // (compiler barrier: without it the block-invariant LDS reads of the light loop — sphere centres, plane
       // normals — are hoisted out of the chunk loop into ~40 long-lived VGPRs, which costs the second wave per SIMD)
       asm volatile("" ::: "memory");
       const float* lg = s_lightf[li];
       const float* ll = s_lightl[li];
-      const f3 tl = mkf((lg[0] - pf.x) + (ll[0] - pl.x), (lg[1] - pf.y) + (ll[1] - pl.y), (lg[2] - pf.z) + (ll[2] - pl.z));
+      const f3 tl = mkf((nlx - pf.x) + (nmx - pl.x), (nly - pf.y) + (nmy - pl.y), (nlz - pf.z) + (nmz - pl.z));
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
@@ -933,11 +940,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const float qa = T0 - RL * RL, rqa = raw_rcp(qa);
         const float rT0 = rl * rl;                                             // 1 / |tl|^2
         const float hw2 = 0.5005f * radius * 1.4143f;                         // |oi|, |oj| <= radius / 2; |B| + |C| <= sqrt2 sqrt(B^2 + C^2)
+        // (the next slot's centre is read from LDS while this one is worked on: a read + wait per slot otherwise)
+        float4 sf_n = s_sphf[0], sl_n = s_sphl[0];
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
           a_AB[k] = mk2(0.0f, 0.0f); a_Cc[k].x = 0.0f;
+          const float4 sf = sf_n, sl = sl_n;
+          if (k + 1 < MAXS) { sf_n = s_sphf[k + 1]; sl_n = s_sphl[k + 1]; }
           if (k < nS && ((wcan >> k) & 1u)) {
-            const float4 sf = s_sphf[k], sl = s_sphl[k];
             const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
             const float A_ = dotf(oc, tl), cc_ = a_Cc[k].y, r = sf.w;
             a_AB[k].x = A_;
@@ -981,11 +991,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             }
         }
         lane_full &= !own_light_inside;
+        float4 pn4[MAXP > 0 ? MAXP : 1];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) pn4[k] = s_plnf[k];
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
           a_D01[k] = mk2(0.0f, 0.0f); a_D2n[k].x = 0.0f;
           if (k < nP) {
-            const float4 nf4 = s_plnf[k];
+            const float4 nf4 = pn4[k];
             const f3 N = mkf(nf4.x, nf4.y, nf4.z);
             const float D0_ = dotf(N, tl), num_ = a_D2n[k].y;
             a_D01[k].x = D0_;
@@ -1026,10 +1039,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const bool lo_path = (RT_DBG(fp) & 4u) || __any(active & behind & (OPAQUE ? (own_is_plane | own_light_inside) : true));
       // (the slow path reads the coefficients of each lane's OWN sphere, whether or not the wave tests that sphere)
       const uint32_t bc_mask = lo_path ? (wcan | act) : act;
+      float4 sfb_n = s_sphf[0], slb_n = s_sphl[0];
 #pragma unroll
       for (int k = 0; k < MAXS; ++k) {
+        const float4 sf = sfb_n, sl = slb_n;
+        if (k + 1 < MAXS) { sfb_n = s_sphf[k + 1]; slb_n = s_sphl[k + 1]; }
         if (k < nS && ((bc_mask >> k) & 1u)) {
-          const float4 sf = s_sphf[k], sl = s_sphl[k];
           const f3 oc = mkf((pf.x - sf.x) + (pl.x - sl.x), (pf.y - sf.y) + (pl.y - sl.y), (pf.z - sf.z) + (pl.z - sl.z));
           a_AB[k].y = dotf(oc, right); a_Cc[k].x = dotf(oc, up);
         }
@@ -1194,6 +1209,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
 #endif
       }
       if (undecided) total = 0.0f;
+      {
+        const int ln = li + 1 < sc.nL ? li + 1 : li;
+        nlx = s_lightf[ln][0]; nly = s_lightf[ln][1]; nlz = s_lightf[ln][2]; nmx = s_lightl[ln][0]; nmy = s_lightl[ln][1]; nmz = s_lightl[ln][2];
+      }
       const float T = total * inv_cells;
       const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
