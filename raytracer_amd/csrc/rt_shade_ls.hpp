@@ -466,6 +466,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // crossing at the sample end of a shadow segment (tau = 1) is then possible, which fp32 does not decide
   __shared__ uint32_t s_lstr[LS_MAX_LIGHTS];
   __shared__ float s_labs[LS_MAX_LIGHTS];                     // |Lp|_1
+  // the same per-light values packed for the light loop, which reads a light with THREE 16-byte broadcast reads one light
+  // ahead and one more after the sample loop (instead of ~17 four-byte reads in ~6 read + wait groups: a wave's LDS
+  // latency is exposed at two waves per SIMD — 37 % of the culled frame's wave cycles were s_waitcnt waits, 250 LDS
+  // instructions per 64-hit chunk at ~55 cycles each):
+  //   [0] position (high parts), radius   [1] position (low parts), |Lp|_1   [2] bits of s_lin, s_lout, s_lstr, shadow intensity
+  //   [3] colour, specular intensity
+  __shared__ float4 s_lt[LS_MAX_LIGHTS][4];
   __shared__ double s_matd[LS_MAX_MATS][MAT_STRIDE];
   // exact fp64 geometry of each lane's hit, parked for the spawn step and the re-test queue (hit point, normal, ray
   // direction, weight): cheaper than keeping 24 VGPRs live through the light loop or recomputing the divisions
@@ -585,6 +592,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         if (in_big && !in_small) str_ |= 0x1000000u << k;
       }
       s_lin[li] = in_; s_lout[li] = out_; s_lstr[li] = str_; s_labs[li] = labs;
+      {
+        const float hx = (float)L[0], hy = (float)L[1], hz = (float)L[2];
+        s_lt[li][0] = make_float4(hx, hy, hz, (float)L[8]);
+        s_lt[li][1] = make_float4((float)(L[0] - (double)hx), (float)(L[1] - (double)hy), (float)(L[2] - (double)hz), labs);
+        s_lt[li][2] = make_float4(__uint_as_float(in_), __uint_as_float(out_), __uint_as_float(str_), (float)L[7]);
+        s_lt[li][3] = make_float4((float)L[3], (float)L[4], (float)L[5], (float)L[6]);
+      }
     }
     __syncthreads();
   }
@@ -656,6 +670,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       h = (uint32_t)lo_ * seg_cap + off;       // slot in the queue
     }
     long long ck_t = prof ? clock64() : 0;
+    // (the row set's divisors pass through an empty asm statement per chunk: otherwise the reciprocals of the pixel-index
+    // divisions — loop invariant, one VGPR each — are kept across the whole chunk loop, where they are spilled to scratch
+    // and every chunk waits ~400 cycles for their reload; recomputing them costs ~10 instructions each)
+    RowSet rs_l = fp.rs;
+    asm volatile("" : "+s"(rs_l.W), "+s"(rs_l.rows), "+s"(rs_l.block_rows));
     // ---------------------------------------------------------------- phase 1: per-hit setup ---
     v2f a_AB[MAXS], a_Cc[MAXS], a_Sg[(MAXS + 1) / 2];
     float a_tauS[MAXS];
@@ -675,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     RayIn r; r.o = r.d = r.w = mk3(0, 0, 0); r.lp = 0;
     if (fused) {
       // (the idle lanes of the frame's last chunk trace a copy of its last pixel: nearest_coherent votes per wave)
-      r = load_ray(0, active ? h : count - 1u, cam, fp.rs, q);
+      r = load_ray(0, active ? h : count - 1u, cam, rs_l, q);
       int k_ = -1;
       hr.t = nearest_coherent(P, nS, nP, nB, r.o, r.d, &k_, fp.plane_thr);
       hr.prim = k_;
@@ -689,7 +708,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       fused_hits += (uint32_t)__popcll(__ballot(active));
     } else if (active && !qin) {
       hr = hits[h];
-      r = load_ray(level, hr.slot, cam, fp.rs, q);
+      r = load_ray(level, hr.slot, cam, rs_l, q);
     }
     if (fused && !__any(active)) {             // a tile of background pixels: nothing to shade
       uint32_t nc_ = 0;
@@ -727,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       p = mk3(hp.x + n.x * EPS, hp.y + n.y * EPS, hp.z + n.z * EPS);
       nf = tof(n);
       mat_idx = op.mat; own = hr.prim; own_is_plane = op.type == 1;
-      lp = r.lp; gpix = global_pixel(fp.rs, lp);
+      lp = r.lp; gpix = global_pixel(rs_l, lp);
       wgt = tof(r.w);
       pf = tof(p);
       pl = mkf((float)(p.x - (double)pf.x), (float)(p.y - (double)pf.y), (float)(p.z - (double)pf.z));
@@ -876,7 +895,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       for (int o_ = 32; o_ > 0; o_ >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o_));
       const float rho = raw_sqrt(r2) * 1.0001f + 1e-5f * (1.0f + fabsf(cw.x) + fabsf(cw.y) + fabsf(cw.z));
       bool may = false;
-      const int j = (int)lane;
+      int j = (int)lane;
+      asm volatile("" : "+v"(j));           // (likewise: lane j's (light, sphere) and their LDS addresses are formed per chunk, not kept)
       if (j < nS * sc.nL) {
         const int li = j / nS, k = j - li * nS;
         const float* lg = s_lightf[li];
@@ -897,18 +917,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     // ------------------------------------------------------------- phase 2: lights & shadows ---
     float dif0 = 0, dif1 = 0, dif2 = 0, spc0 = 0, spc1 = 0, spc2 = 0;
     // (the next light's position is read from LDS while this light's Phong terms are formed, see the end of the loop body)
-    float nlx = s_lightf[0][0], nly = s_lightf[0][1], nlz = s_lightf[0][2], nmx = s_lightl[0][0], nmy = s_lightl[0][1], nmz = s_lightl[0][2];
+    float4 nL0 = s_lt[0][0], nL1 = s_lt[0][1], nL2 = s_lt[0][2];
     for (int li = 0; li < sc.nL; ++li) {
       // (compiler barrier: without it the block-invariant LDS reads of the light loop — sphere centres, plane
       // normals — are hoisted out of the chunk loop into ~40 long-lived VGPRs, which costs the second wave per SIMD)
       asm volatile("" ::: "memory");
-      const float* lg = s_lightf[li];
-      const float* ll = s_lightl[li];
-      const f3 tl = mkf((nlx - pf.x) + (nmx - pl.x), (nly - pf.y) + (nmy - pl.y), (nlz - pf.z) + (nmz - pl.z));
+      const float4 L0 = nL0, L1 = nL1, L2 = nL2;
+      const uint32_t l_in = __float_as_uint(L2.x), l_out = __float_as_uint(L2.y), l_str = __float_as_uint(L2.z);
+      const float l_shadow = L2.w, l_abs = L1.w;
+      const f3 tl = mkf((L0.x - pf.x) + (L1.x - pl.x), (L0.y - pf.y) + (L1.y - pl.y), (L0.z - pf.z) + (L1.z - pl.z));
       const float T0 = dotf(tl, tl);
       const float rl = raw_rsq(T0);
       const f3 ld = scalef(tl, rl);                                         // ray_tracer.py:198-213
-      const float radius = lg[8];
+      const float radius = L0.w;
       const float nt = dotf(nf, tl);
       const uint32_t wcan = (nS * sc.nL <= 64 && !brute) ? (uint32_t)(pair_can >> (li * nS)) : 0xFFFFFFFFu;   // spheres this wave may touch
       float total = (float)n_cells;
@@ -930,7 +951,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const bool behind = nt < 0.71f * radius;
       // the hit point and (some sample of) the light possibly on different sides of the hit's own sphere /
       // box: then the only crossing between them is the one at the hit point itself
-      bool own_light_inside = ((own_out_bit & s_lin[li]) | (own_in_bit & s_lout[li])) != 0u;
+      bool own_light_inside = ((own_out_bit & l_in) | (own_in_bit & l_out)) != 0u;
       uint32_t act = 0;
       const float RL = 0.7072f * radius * 1.001f;
       {
@@ -1059,8 +1080,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       }
       if (prof) { const long long t = clock64(); ck_setup += t - ck_t; ck_t = t; }
       const float4* cells = s_cells + li * ((n_cells + 1) >> 1);
-      str_act = act & s_lstr[li];
-      if (MAXB > 0) str_act |= s_lstr[li] & 0xFF000000u;
+      str_act = act & l_str;
+      if (MAXB > 0) str_act |= l_str & 0xFF000000u;
       // scenes with transparency: the reference's walk multiplies at most 20 crossings (ray_tracer.py:257), the sample loop
       // all of them — a (wave, light) whose candidate set could give a segment more than that goes to the exact walk
       // (only the 12- / 16-sphere instantiations can get there; the sequential renderer's walk has no cap)
@@ -1101,7 +1122,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         LsFlags fl = ls_flags_init();
         // all-opaque scenes without boxes: the square-root-free loop when every candidate sphere has the wave's shadow origins
         // outside it (or is the hit's own) and the light's samples outside it (ls_light_sum_simple); wave-uniform
-        const bool simple = OPAQUE && MAXB == 0 && !lo_path && !(RT_DBG(fp) & 64u) && ((act & 0xFFFFu & s_lin[li]) == 0u) &&
+        const bool simple = OPAQUE && MAXB == 0 && !lo_path && !(RT_DBG(fp) & 64u) && ((act & 0xFFFFu & l_in) == 0u) &&
                             !__any(active & ((bad_cc & act) != 0u));
         if (lo_path)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
@@ -1160,7 +1181,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // also undecided in fp32: the light within 3 sample-square radii of the hit (|ts| is then not comparable
         // to |tl|, which the bounds assume)
         // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
-        const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + s_labs[li]);
+        const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + l_abs);
         // (ls_light_sum_simple counts blocked samples in floats: a sum that is not a whole number had a denormal decision value)
         undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far | (simple & (total != floorf(total)));
         if (RT_DBG(fp) & (1u << 23))    // cause bits: 1 grazing discriminant, 2 root at the origin, 4 parallel plane, 8 light close, 16 far
@@ -1209,35 +1230,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
 #endif
       }
       if (undecided) total = 0.0f;
+      const float4 L3 = s_lt[li][3];                         // colour, specular intensity: for the Phong terms below
       {
-        const int ln = li + 1 < sc.nL ? li + 1 : li;
-        nlx = s_lightf[ln][0]; nly = s_lightf[ln][1]; nlz = s_lightf[ln][2]; nmx = s_lightl[ln][0]; nmy = s_lightl[ln][1]; nmz = s_lightl[ln][2];
+        const int ln = li + 1 < sc.nL ? li + 1 : li;        // the next light, read while this one's Phong terms are formed
+        nL0 = s_lt[ln][0]; nL1 = s_lt[ln][1]; nL2 = s_lt[ln][2];
       }
       const float T = total * inv_cells;
-      const float I = fmaf(lg[7], T, 1.0f - lg[7]);                                       // ray_tracer.py:543
+      const float I = fmaf(l_shadow, T, 1.0f - l_shadow);                                 // ray_tracer.py:543
       // light direction from the offset point p instead of the un-offset hit point (1e-6 apart)
       const float ndl = fmaxf(nt * rl, 0.0f);
       const float s1 = I * ndl;
-      dif0 = fmaf(kd0 * lg[3], s1, dif0);
-      dif1 = fmaf(kd1 * lg[4], s1, dif1);
-      dif2 = fmaf(kd2 * lg[5], s1, dif2);
+      dif0 = fmaf(kd0 * L3.x, s1, dif0);
+      dif1 = fmaf(kd1 * L3.y, s1, dif1);
+      dif2 = fmaf(kd2 * L3.z, s1, dif2);
       const float dn = -nt * rl;                                                          // (-l).n
       const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -ld.x), fmaf(-2.0f * dn, nf.y, -ld.y), fmaf(-2.0f * dn, nf.z, -ld.z));
       const float rdv = fmaxf(dotf(rf, v), 0.0f);
       // rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals
       // (v_log_f32 / v_exp_f32, 1 ulp each; log2(0) = -inf -> 0); np.power(0, 0) == 1
       const float pw = (shin == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv));
-      const float s2 = I * pw * lg[6];
-      spc0 = fmaf(ks0 * lg[3], s2, spc0);
-      spc1 = fmaf(ks1 * lg[4], s2, spc1);
-      spc2 = fmaf(ks2 * lg[5], s2, spc2);
+      const float s2 = I * pw * L3.w;
+      spc0 = fmaf(ks0 * L3.x, s2, spc0);
+      spc1 = fmaf(ks1 * L3.y, s2, spc1);
+      spc2 = fmaf(ks2 * L3.z, s2, spc2);
       if (__any(undecided)) {
         // colour per unit of T of this (hit, light): d(colour)/dI * shadow_intensity, times weight and (1 - transparency)
-        const float cm = lg[7] * one_m, sp = pw * lg[6];
+        const float cm = l_shadow * one_m, sp = pw * L3.w;
         const uint32_t t_ = threadIdx.x;
         const d3 pe = mk3(s_geo[0][t_] + s_geo[3][t_] * EPS, s_geo[1][t_] + s_geo[4][t_] * EPS, s_geo[2][t_] + s_geo[5][t_] * EPS);
-        queue_fix(undecided, fix, C, fp, pe, wgt.x * cm * lg[3] * fmaf(kd0, ndl, ks0 * sp), wgt.y * cm * lg[4] * fmaf(kd1, ndl, ks1 * sp),
-                  wgt.z * cm * lg[5] * fmaf(kd2, ndl, ks2 * sp), lp, gpix, level, li);
+        queue_fix(undecided, fix, C, fp, pe, wgt.x * cm * L3.x * fmaf(kd0, ndl, ks0 * sp), wgt.y * cm * L3.y * fmaf(kd1, ndl, ks1 * sp),
+                  wgt.z * cm * L3.z * fmaf(kd2, ndl, ks2 * sp), lp, gpix, level, li);
       }
     }
 

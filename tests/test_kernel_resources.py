@@ -13,7 +13,7 @@ from conftest import ROOT
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
-@pytest.mark.parametrize("fall,max_spill", [(2, 12), (3, 4)])      # level 0 / deeper levels of a fused frame
+@pytest.mark.parametrize("fall,max_spill", [(2, 6), (3, 2)])      # level 0 / deeper levels of a fused frame
 def test_headline_kernel_keeps_two_waves_per_simd(fall, max_spill):
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "one_kernel.sh"), f"rt::k_shade_ls<6, 2, 0, true, {fall}>", "rt_shade_ls.hpp"],
                          capture_output=True, text=True, timeout=600).stdout
