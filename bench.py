@@ -7,9 +7,9 @@
 A step = one frame: every rank renders its interleaved row blocks of the frame into device memory
 (the scene is already resident in HBM) and, for N > 1, the tiles are gathered to rank 0 over RCCL.
 The frame is fixed as N grows (strong scaling).  Rank 0 prints ONE JSON line.
-For every N two frames are in flight on each rank (two scene handles on two non-blocking streams: the next frame's
-level 0 fills the tails of this frame's small launches; for N > 1 the gather of frame k also overlaps the render of
-k + 1), so `value` / `ms_per_step` are throughput numbers; `one_frame_at_a_time` (N = 1) carries the frame time of the
+For every N several frames (RT_BENCH_IN_FLIGHT, default 3) are in flight on each rank (one scene handle and one
+non-blocking stream per frame in flight: the next frames' level 0 fills the tails of this frame's small launches; for
+N > 1 the gather of frame k also overlaps the render of k + 1 ...), so `value` / `ms_per_step` are throughput numbers; `one_frame_at_a_time` (N = 1) carries the frame time of the
 same frames rendered one after the other on one stream, and RT_BENCH_PIPELINE=0 makes that the headline.
 
 metric/value: Mrays/s, rays = radiance rays + shadow rays of the frame, whole job.
@@ -174,18 +174,21 @@ def main():
     # non-blocking stream, which torch's default stream does NOT order against).  N = 1 needs no sharing: the timed
     # region ends with a device-wide synchronize.  N > 1: the render and the gather run on ONE explicit torch stream
     # (or on two with events between them when pipelined), so the gather can never read a half-rendered tile.
-    serial_stream = new_stream(dev) if world > 1 else None
+    # Frames in flight (every N): frames alternate between `depth` scene handles (each with its own workspace, render
+    # stream and tile buffer), so the kernels of the next frames fill the tails of frame k's small launches, and for
+    # N > 1 the gather of frame k (comm stream) overlaps the render of frame k+1.  Measured on one GPU with one rank's
+    # row set (tools/part_in_flight_probe.py): 3 in flight beats 2 by 2 % at N = 1 and by 6-9 % on the row sets of
+    # N = 4 / 8 (whose launches are short and latency bound); 4 is worse than 3 (the runtime has 4 hardware queues).
+    # RT_BENCH_PIPELINE=0 serialises everything on one stream (frame latency).
+    pipelined = os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
+    depth = max(2, min(8, int(os.environ.get("RT_BENCH_IN_FLIGHT", "3")))) if pipelined else 1
+    serial_stream = new_stream(dev) if (world > 1 and not pipelined) else None
     if serial_stream is not None:
         gs.set_stream(serial_stream.cuda_stream)
 
     tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
     dtype = torch.float32 if precision == "fp32" else torch.float64
-    # N > 1: two frames are in flight — frames alternate between two scene handles (each with its own
-    # workspace, render stream and tile buffer), so the kernels of frame k+1 fill the tails of frame k's
-    # small launches, and the gather of frame k (comm stream) overlaps the render of frame k+1.
-    # RT_BENCH_PIPELINE=0 serialises everything on one stream (frame latency).
-    pipelined = os.environ.get("RT_BENCH_PIPELINE", "1") != "0"
-    n_buf = 2 if pipelined else 1
+    n_buf = depth
     tiles = [torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev) for _ in range(n_buf)]
     tile = tiles[0]
     frame = torch.empty((H, W, 3), dtype=dtype, device=dev) if (world > 1 and rank == 0) else None
@@ -196,17 +199,14 @@ def main():
         if world == 1 and pipelined:      # (N = 1: the event-timed frames come from a serial loop after the timed region)
             return _lib.RT_FLAG_ASYNC
         return _lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0)
-    scenes = [gs]
-    if pipelined and world == 1:
-        scenes.append(GpuScene(packed, device=local_rank))      # (each handle renders on its own private non-blocking stream)
-    elif pipelined:
-        scenes.append(GpuScene(packed, device=local_rank))
-        render_streams = [new_stream(dev), new_stream(dev)]
+    scenes = [gs] + [GpuScene(packed, device=local_rank) for _ in range(depth - 1)]      # (N = 1: each handle renders on its own private non-blocking stream)
+    if pipelined and world > 1:
+        render_streams = [new_stream(dev) for _ in range(depth)]
         comm_stream = new_stream(dev)
         for sc_, st_ in zip(scenes, render_streams):
             sc_.set_stream(st_.cuda_stream)
-        rendered = [torch.cuda.Event() for _ in range(2)]
-        tile_free = [None, None]
+        rendered = [torch.cuda.Event() for _ in range(depth)]
+        tile_free = [None] * depth
     frame_no = [0]
     gather_events = []      # (start, end) on the stream the gather runs on, for the frames whose kernels are event-timed too
 
@@ -233,14 +233,14 @@ def main():
                 with torch.cuda.stream(serial_stream):      # same stream as the kernels: ordered after them
                     timed_gather(serial_stream, k, tile, tiling, rank, out=frame, scratch=scratch, via_host=(backend != "nccl"))
             return
-        b = k & 1
+        b = k % depth
         if world == 1:
             scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
                              out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
             return
         render_stream = render_streams[b]
         if tile_free[b] is not None:
-            render_stream.wait_event(tile_free[b])          # the gather of frame k-2 has read this tile
+            render_stream.wait_event(tile_free[b])          # the gather of frame k-depth has read this tile
         scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
                          part=rank, n_parts=world, out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
         rendered[b].record(render_stream)
@@ -318,7 +318,7 @@ def main():
         multi = {"compute_ms": {"per_rank": [round(p_[0], 4) for p_ in per], "max": round(max(p_[0] for p_ in per), 4), "min": round(min(p_[0] for p_ in per), 4)},
                  "gather_ms": {"per_rank": [round(p_[1], 4) for p_ in per], "rank0": round(per[0][1], 4)},
                  "rows_per_rank": [int(p_[2]) for p_ in per], "tile_rows_gathered": tiling.max_rows,
-                 "frames_with_events": len(timed_mine), "pipelined": bool(pipelined),
+                 "frames_with_events": len(timed_mine), "pipelined": bool(pipelined), "frames_in_flight": depth,
                  "note": "compute_ms: first kernel start -> last kernel end of a rank's frame (HIP events on its render stream); gather_ms: "
                          "torch.distributed.gather of the padded tiles + reassembly on the stream it runs on (rank 0 waits for the slowest peer)"}
 
@@ -443,8 +443,9 @@ def main():
             "config": {"workload": desc, "rays_per_frame": int(total_rays), "radiance_rays": int(rays), "hits": int(hits),
                        "shadow_rays": int(shadow), "row_blocks": args.block_rows,
                        "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")
-                                      + (", 2 frames in flight (two streams; gather k overlaps render k+1)" if (pipelined and world > 1) else "")
-                                      + (", 2 frames in flight (two scene handles, two streams)" if (pipelined and world == 1) else "")},
+                                      + (f", {depth} frames in flight (a scene handle and a stream each; gather k overlaps render k+1)" if (pipelined and world > 1) else "")
+                                      + (f", {depth} frames in flight (a scene handle and a stream each)" if (pipelined and world == 1) else ""),
+                       "frames_in_flight": depth},
             "roofline": roofline,
         }
         if world > 1 and roofline is not None:
