@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--workload", default="pool4k", choices=sorted(WORKLOADS))
     ap.add_argument("--block-rows", type=int, default=0,
                     help="rows per interleaved block (0 = 8, the height of the kernels' pixel tiles)")
+    ap.add_argument("--out-format", default="native", choices=["native", "u8"],
+                    help="frame format in device memory, every N: native = float32 / float64 linear radiance (what render_vectorized returns; "
+                         "the default), u8 = the 8-bit image of save_image quantised on the device (SURVEY 8 f1: the gather moves 4x fewer bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -187,7 +190,9 @@ def main():
         gs.set_stream(serial_stream.cuda_stream)
 
     tiling = cache_row_indices(RowTiling(H, W, world, args.block_rows), dev)
-    dtype = torch.float32 if precision == "fp32" else torch.float64
+    u8 = args.out_format == "u8"
+    dtype = torch.uint8 if u8 else (torch.float32 if precision == "fp32" else torch.float64)
+    common = dict(precision=precision, jitter=1234, out_format="u8" if u8 else None)      # of every render call into a tile / frame buffer
     n_buf = depth
     tiles = [torch.empty((tiling.max_rows, W, 3), dtype=dtype, device=dev) for _ in range(n_buf)]
     tile = tiles[0]
@@ -227,7 +232,7 @@ def main():
         k = frame_no[0]; frame_no[0] += 1
         flags = flags_of(k)
         if not pipelined:
-            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+            gs.render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows,
                       part=rank, n_parts=world, out_ptr=tile.data_ptr(), flags=flags, stats=stats)
             if world > 1:
                 with torch.cuda.stream(serial_stream):      # same stream as the kernels: ordered after them
@@ -235,13 +240,13 @@ def main():
             return
         b = k % depth
         if world == 1:
-            scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+            scenes[b].render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows,
                              out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
             return
         render_stream = render_streams[b]
         if tile_free[b] is not None:
             render_stream.wait_event(tile_free[b])          # the gather of frame k-depth has read this tile
-        scenes[b].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+        scenes[b].render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows,
                          part=rank, n_parts=world, out_ptr=tiles[b].data_ptr(), flags=flags, stats=stats)
         rendered[b].record(render_stream)
         with torch.cuda.stream(comm_stream):
@@ -280,12 +285,12 @@ def main():
     if world == 1 and pipelined:
         ser_stats = [_lib.Stats() for _ in range(args.steps)]
         for _ in range(3):
-            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+            gs.render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows,
                       out_ptr=tile.data_ptr(), flags=_lib.RT_FLAG_ASYNC)
         gs.sync(); torch.cuda.synchronize()
         ts = time.perf_counter()
         for k, s_ in enumerate(ser_stats):
-            gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows, out_ptr=tile.data_ptr(),
+            gs.render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows, out_ptr=tile.data_ptr(),
                       flags=_lib.RT_FLAG_ASYNC | (_lib.RT_FLAG_TIMING if (not args.no_timing and k % every == 0) else 0), stats=s_)
         torch.cuda.synchronize()
         serial = (time.perf_counter() - ts) / args.steps * 1e3
@@ -326,9 +331,9 @@ def main():
     if not args.no_verify and world > 1 and rank == 0:
         full = torch.empty((H, W, 3), dtype=dtype, device=dev)
         torch.cuda.synchronize()
-        gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=full.data_ptr())
+        gs.render(cam, W, H, n_shadow, max_depth, **common, out_ptr=full.data_ptr())
         torch.cuda.synchronize()
-        verify = {"max_abs_diff_vs_single_gpu_frame": float((full - frame).abs().max()), "ranks": dist.get_world_size(), "backend": backend}
+        verify = {"max_abs_diff_vs_single_gpu_frame": float((full.double() - frame.double()).abs().max()), "ranks": dist.get_world_size(), "backend": backend}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -360,7 +365,7 @@ def main():
                 bs = []
                 for _ in range(args.brute_frames + 1):
                     st_b = _lib.Stats()
-                    gs.render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, out_ptr=tile.data_ptr(),
+                    gs.render(cam, W, H, n_shadow, max_depth, **common, out_ptr=tile.data_ptr(),
                               flags=_lib.RT_FLAG_TIMING | _lib.RT_FLAG_BRUTE_FORCE, stats=st_b)
                     bs.append(st_b)
                 bs = bs[1:]                                   # first one: warm-up
@@ -426,7 +431,7 @@ def main():
             roofline = {"bound": "valu", "kernel": kernel,
                         "flop_model": "brute-force algorithmic flops of SURVEY.md 8(d): every query tests every surface",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac, "frac_basis": basis,
-                        "traffic": traffic, "traffic_per_frame": traffic_frame, "algorithmic_bytes_per_frame": int(W * H * 3 * (4 if precision == "fp32" else 8)),
+                        "traffic": traffic, "traffic_per_frame": traffic_frame, "algorithmic_bytes_per_frame": int(W * H * 3 * (1 if u8 else 4 if precision == "fp32" else 8)),
                         "brute_force": brute, "culled": culled, "executed": executed,
                         "flops_per_launch": flops_frame / launches, "frames_with_events": len(timed),
                         "rays_traced_in_shade_kernel": fused_rays,
@@ -445,7 +450,7 @@ def main():
                        "parallelism": f"row-tiled x{world}" + (f", {backend} gather to rank 0" if world > 1 else "")
                                       + (f", {depth} frames in flight (a scene handle and a stream each; gather k overlaps render k+1)" if (pipelined and world > 1) else "")
                                       + (f", {depth} frames in flight (a scene handle and a stream each)" if (pipelined and world == 1) else ""),
-                       "frames_in_flight": depth},
+                       "frames_in_flight": depth, "out_format": "u8" if u8 else ("f32" if precision == "fp32" else "f64")},
             "roofline": roofline,
         }
         if world > 1 and roofline is not None:
@@ -470,7 +475,7 @@ def main():
                 tiles2 = [tile, torch.empty_like(tile)]
                 def two(k_frames):
                     for k in range(k_frames):
-                        pair[k & 1].render(cam, W, H, n_shadow, max_depth, precision=precision, jitter=1234, block_rows=args.block_rows,
+                        pair[k & 1].render(cam, W, H, n_shadow, max_depth, **common, block_rows=args.block_rows,
                                            out_ptr=tiles2[k & 1].data_ptr(), flags=_lib.RT_FLAG_ASYNC)
                 two(8)
                 for sc_ in pair:

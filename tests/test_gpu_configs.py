@@ -148,8 +148,8 @@ def test_render_from_load_packed(tmp_path, oracle, name, n, depth):
 
 
 # --------------------------------------------------------------------------- e: N = 2 rehearsal ----
-@pytest.mark.parametrize("pipeline", ["1", "0"])
-def test_bench_two_ranks_on_one_device(pipeline):
+@pytest.mark.parametrize("pipeline,fmt", [("1", "native"), ("0", "native"), ("1", "u8")])
+def test_bench_two_ranks_on_one_device(pipeline, fmt):
     """bench.py's N > 1 path (interleaved row blocks per rank, gather to rank 0, reassembly) with both ranks on
     cuda:0 and the gather through gloo: the gathered frame must equal the single-GPU frame exactly (fp64 workload:
     every pixel receives at most one contribution per level, so there is no accumulation-order rounding)."""
@@ -158,7 +158,7 @@ def test_bench_two_ranks_on_one_device(pipeline):
     env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_ONE_DEVICE="1", RT_BENCH_PIPELINE=pipeline, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--prewarm", "2", "--workload", "pool500"]
+           "--prewarm", "2", "--workload", "pool500", "--out-format", fmt]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
@@ -172,3 +172,5 @@ def test_bench_two_ranks_on_one_device(pipeline):
     assert len(m["compute_ms"]["per_rank"]) == 2 and len(m["gather_ms"]["per_rank"]) == 2 and m["frames_with_events"] >= 1
     assert m["compute_ms"]["max"] >= m["compute_ms"]["min"] > 0.0 and m["gather_ms"]["rank0"] > 0.0
     assert sum(m["rows_per_rank"]) == 500 and m["pipelined"] == (pipeline == "1")
+    assert m["frames_in_flight"] == (3 if pipeline == "1" else 1)
+    assert out["config"]["out_format"] == ("u8" if fmt == "u8" else "f64")
