@@ -124,6 +124,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
   int* const wl = s_wleaves + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_LEAF_CAP);
   __shared__ int s_wrecs[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_REC_CAP];
   int* const wr = s_wrecs + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_REC_CAP);
+  // beside each listed record: (Lp - centre, R0) of its bound for this light — the hit-independent part of the lanes' fan
+  // test (fan_may_touch), formed once by the lane that lists the record.  The lanes' filter loop then reads LDS only: with
+  // the bound fetched from global memory per (lane, record) every step of that loop waited for a load whose address came
+  // from an LDS read (~1 us per listed record and wave; 25 % of the kernel's wave cycles)
+  __shared__ float4 s_wrb[LDS_SCENE ? 1 : (BLOCK / 64) * WAVE_REC_CAP];
+  float4* const wrb = s_wrb + (LDS_SCENE ? 0 : (threadIdx.x >> 6) * WAVE_REC_CAP);
   const Prim* P = stage_scene<LDS_SCENE>(sc, s_prims);
   const Accel ac = stage_accel<LDS_SCENE>(sc, s_nodes);
   const float scene_m = sc.scene_m;   // scales the fp32 slack of the node tests
@@ -274,11 +280,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             for (int l0 = 0; l0 < n_wl && n_wr >= 0; l0 += 8) {
               const int slot = l0 + (int)(lane >> 3), j = (int)(lane & 7u);
               bool may = false; int rec = 0;
+              float4 wv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
               if (slot < n_wl) {
                 const BvhNode nd = load_node(ac, wl[slot]);
                 if (j < nd.count()) {
                   rec = nd.first + j;
                   const float4 b = ac.pbound[rec];
+                  {   // exactly the first lines of fan_may_touch (below)
+                    const float wx_ = (float)lg[0] - b.x, wy_ = (float)lg[1] - b.y, wz_ = (float)lg[2] - b.z;
+                    wv = make_float4(wx_, wy_, wz_, b.w + RLw + 4e-5f * (1.0f + fabsf(wx_) + fabsf(wy_) + fabsf(wz_)));
+                  }
                   const f3 ow = mkf(cw.x - b.x, cw.y - b.y, cw.z - b.z);
                   const float w0 = b.w + rho + gs;
                   const float o2 = dotf(ow, ow), qb = dotf(ow, tw) - w0 * dlw;
@@ -290,12 +301,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
               const unsigned long long m = __ballot(may);
               const int cnt = __popcll(m);
               if (n_wr + cnt > WAVE_REC_CAP) { n_wr = -1; break; }
-              if (may) wr[n_wr + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rec;
+              if (may) {
+                const int at = n_wr + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                wr[at] = rec; wrb[at] = wv;
+              }
               n_wr += cnt;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            n_wr = __builtin_amdgcn_readfirstlane(n_wr);      // (wave-uniform by construction: lets the lanes' filter loop run on scalar counters)
           }
           if ((RT_DBG(fp) & 128u) && lane == 0) {
             atomicAdd(&C->dbg[0], 1ull); atomicAdd(&C->dbg[1], n_wl < 0 ? 1ull : 0ull); atomicAdd(&C->dbg[2], (unsigned long long)(n_wl < 0 ? 0 : n_wl));
@@ -509,15 +524,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             const float qa = dotf(tl, tl) - RL * RL, rqa = raw_rcp(qa);
             const float Lx = (float)lg[0], Ly = (float)lg[1], Lz = (float)lg[2];
             const float ddx = -tl.x, ddy = -tl.y, ddz = -tl.z;                      // p - Lp
-            auto fan_may_touch = [&](float cx, float cy, float cz, float r) __attribute__((always_inline)) {
+            // (wx, wy, wz) = Lp - centre of the record's bound, R0 = its radius + RL + slack: hit independent (see s_wrb)
+            auto fan_may_touch_rel = [&](float wx, float wy, float wz, float R0) __attribute__((always_inline)) {
               if (RT_DBG(fp) & 16384u) return true;
-              const float wx = Lx - cx, wy = Ly - cy, wz = Lz - cz;
-              const float R0 = r + RL + 4e-5f * (1.0f + fabsf(wx) + fabsf(wy) + fabsf(wz));
               const float qb = fmaf(wz, ddz, fmaf(wy, ddy, wx * ddx)) + RL * R0;
               const float sa = fminf(fmaxf(-qb * rqa, 0.0f), 1.0f);                // min of |w + s d|^2 - (R0 - s RL)^2
               const float xx = fmaf(sa, ddx, wx), xy = fmaf(sa, ddy, wy), xz = fmaf(sa, ddz, wz);
-              const float wr = fmaf(-sa, RL, R0);
-              return bool((qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= wr * wr));
+              const float wrad = fmaf(-sa, RL, R0);
+              return bool((qa <= 0.0f) | (fmaf(xz, xz, fmaf(xy, xy, xx * xx)) <= wrad * wrad));
+            };
+            auto fan_may_touch = [&](float cx, float cy, float cz, float r) __attribute__((always_inline)) {
+              const float wx = Lx - cx, wy = Ly - cy, wz = Lz - cz;
+              return fan_may_touch_rel(wx, wy, wz, r + RL + 4e-5f * (1.0f + fabsf(wx) + fabsf(wy) + fabsf(wz)));
             };
             // node boxes: segment Lp -> p against the box grown by the fan radius (+ fp32 slack), 0 <= s <= 1
             const float gx = fabsf(ddx) > 1e-20f ? raw_rcp(ddx) : 1e30f, gy = fabsf(ddy) > 1e-20f ? raw_rcp(ddy) : 1e30f,
@@ -596,11 +614,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             while (!finished) {
               if (n_wr >= 0) {
                 // the wave's record list: each lane keeps the records its own fan may touch
-                for (; we < n_wr && !__any(n_cand >= CAND_LIST); ++we) {
-                  const int k = wr[we];
-                  const float4 b = ac.pbound[k];
-                  if (RT_DBG(fp)) ++it2;
-                  if (fan_may_touch(b.x, b.y, b.z, b.w)) { my_cand[n_cand * BLOCK] = (uint32_t)k; ++n_cand; }
+                if (we < n_wr) {
+                  float4 nx = wrb[we];                                        // (broadcast reads, one entry ahead)
+                  for (; we < n_wr && !__any(n_cand >= CAND_LIST); ++we) {
+                    const float4 b = nx;
+                    nx = wrb[we + 1 < n_wr ? we + 1 : we];
+                    if (RT_DBG(fp)) ++it2;
+                    if (fan_may_touch_rel(b.x, b.y, b.z, b.w)) { my_cand[n_cand * BLOCK] = (uint32_t)wr[we]; ++n_cand; }
+                  }
                 }
                 finished = we >= n_wr;
               } else if (!__any(le < n_leaf)) {
@@ -798,7 +819,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         const float rdv = fmaxf(dotf(rf, v), 0.0f);
         const float shin = (float)mat[9];
         // np.power(0, 0) == 1; the sequential renderer adds the specular term only for r.v > 0 (ray_tracer.py:356-359)
-        const float pw = rdv > 0.0f ? (shin == 0.0f ? 1.0f : powf(rdv, shin)) : ((shin == 0.0f && !fp.sequential) ? 1.0f : 0.0f);
+        // (rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals, as in k_shade_ls: 1 ulp each,
+        // relative error <= shininess * 2^-22 — far inside the 8-bit tolerance; powf() is ~70 instructions per (hit, light))
+        const float pw = rdv > 0.0f ? (shin == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(shin * __builtin_amdgcn_logf(rdv))) : ((shin == 0.0f && !fp.sequential) ? 1.0f : 0.0f);
         const float s2 = I * pw * (float)lg[6];
         spc[0] = fmaf((float)mat[3] * (float)lg[3], s2, spc[0]);
         spc[1] = fmaf((float)mat[4] * (float)lg[4], s2, spc[1]);
