@@ -330,6 +330,15 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
               const float t0 = tn.x <= tf.x ? (pr.binside[k] ? tf.x : tn.x) : -1.0f;
               const float t1 = tn.y <= tf.y ? (pr.binside[k] ? tf.y : tn.y) : -1.0f;
               m0 = min(m0, __float_as_uint(t0 * d2.x)); m1 = min(m1, __float_as_uint(t1 * d2.y));
+              // The shadow origin ON a face of a box it does not belong to (a floor hit at the foot of a box standing on it:
+              // offset 0, -0 or +-1e-16 after the fp64 subtraction): `binside` and the sign of the entry root are then a matter
+              // of rounding, while the reference's walk decides by its 1e-6 steps (the origin shifted into the box: the exit
+              // face blocks).  An entry root within the bound of zero on EITHER side is therefore not decided in fp32 (the
+              // positive side already was: mlow below); -0.0 has the largest bit pattern and used to pass as "behind".
+              {
+                const float z0 = tn.x <= tf.x ? fabsf(tn.x * d2.x) : 3.0e38f, z1 = tn.y <= tf.y ? fabsf(tn.y * d2.y) : 3.0e38f;
+                mlow = umin3(mlow, __float_as_uint(z0), valid1 ? __float_as_uint(z1) : 0xFFFFFFFFu);
+              }
             } else {
               const float ta = pr.tauB[k];
               const bool ok0 = tn.x <= tf.x, ok1 = tn.y <= tf.y;
@@ -815,6 +824,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
     uint32_t own_in_bit = 0u, own_out_bit = 0u;   // 1 << own if the own sphere is seen from inside / outside
     float oc2max = 0.0f;                          // largest |oc|^2 over the spheres (error bounds)
     uint32_t bad_cc = 0u;                         // spheres the shadow origin is inside of, or whose surface it lies on without being the hit's own (ls_light_sum_simple's precondition)
+                                                  // bits 16+: planes through the shadow origin within rounding (see below)
     float a_sgn[MAXS];
     // (LDS reads one slot ahead, here and in the light loop: with two waves per SIMD a read + wait per slot stalls the wave
     // for the LDS latency each time; the record array has MAXS + MAXP + MAXB entries, so slot k + 1 always exists)
@@ -850,6 +860,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const Prim& s_ = P[nS + k];
         a_D2n[k].y = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
         a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)s_matd[s_.mat][10];
+        // A plane through the shadow origin within rounding (a floor hit on the line where the floor meets a wall; the hit's
+        // own plane is 1e-6 away): its root is +-1e-16, which the reference does not see (t > 1e-6) but whose sign decides
+        // ls_light_sum_simple's test num*den > 0.  Such lanes take ls_light_sum, which leaves a root at the origin to fp64.
+        bad_cc |= fabsf(a_D2n[k].y) < 0.5e-6f ? 0x10000u << k : 0u;
       }
     }
 #pragma unroll
