@@ -386,7 +386,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
             {   // a sample of the light may lie on the sphere (crossing at the far end of the segment)
               const float lx = (float)(lg[0] - s_.a[0]), ly = (float)(lg[1] - s_.a[1]), lz = (float)(lg[2] - s_.a[2]);
               const float dl = raw_sqrt(fmaf(lz, lz, fmaf(ly, ly, lx * lx)));
-              if (fabsf(dl - r_) <= reach + 1e-5f * (dl + r_)) unc = 1.0f;
+              // (and the fp32 error of a root near that end grows with the hit's distance from the sphere: the comparison
+              // t < |S - p| has a margin of half the sample's distance from the surface against e_b + the square root's error,
+              // <= sqrt(kap |b| + kap0) for a decided discriminant — see k_shade_ls; random scene 200792)
+              if (fabsf(dl - r_) <= reach + 1e-5f * (dl + r_) + 2.0f * (e_b + raw_sqrt(fmaf(kap, ocn, kap0)))) unc = 1.0f;
             }
             // a root can only come near the 2e-6 bound when p lies within ~1e-5 of the sphere's surface
             // (t1 t2 = cc): the hit's own sphere, or one touching it at the hit point

@@ -475,6 +475,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
   // crossing at the sample end of a shadow segment (tau = 1) is then possible, which fp32 does not decide
   __shared__ uint32_t s_lstr[LS_MAX_LIGHTS];
   __shared__ float s_labs[LS_MAX_LIGHTS];                     // |Lp|_1
+  // Whether a root lies before or behind the SAMPLE END of a shadow segment (u < |ts|^2) is an fp32 decision whose error
+  // grows with the hit's distance from the sphere (the roots -bt +- sqrt(bt^2 - |ts|^2 cc) cancel); s_lstr only excludes
+  // lights within a fixed 1e-4 of a surface.  With w = S - c the margin of that comparison is |ts|^2 g (|w| + r) / |sq + ts.w|
+  // >= |ts| g / 2 for a sample at distance g from the surface, its error e_b + 4u |ts|^2 + the square root's, which is
+  // <= sqrt(kap |bt| + kap0) once the discriminant is decided; with LsTol's e_b <= 26u Q, kap <= 106u Q (Q = |oc||ts|) that is
+  // <= 2.6e-3 Q, and |ts| >= tsm / 2 here: the decision is safe while |oc| < 96 g.  Per light: 80 x the smallest distance of
+  // its sample square from a sphere's surface; hits farther than that from the spheres leave the pair to the exact walk
+  // unless the loop makes no such decision (ls_light_sum_simple).  (Random scene 200792: a light 0.01 inside a sphere, a
+  // reflected ray's hit 434 units away, the far root counted as a second crossing: 2 levels off.)
+  __shared__ float s_lend[LS_MAX_LIGHTS];
   // the same per-light values packed for the light loop, which reads a light with THREE 16-byte broadcast reads one light
   // ahead and one more after the sample loop (instead of ~17 four-byte reads in ~6 read + wait groups: a wave's LDS
   // latency is exposed at two waves per SIMD — 37 % of the culled frame's wave cycles were s_waitcnt waits, 250 LDS
@@ -577,6 +587,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
       const float labs = (float)(fabs(L[0]) + fabs(L[1]) + fabs(L[2]));
       const double RS = (double)RL + 1e-4 * (1.0 + labs);        // reach of the sample square + slack (see `far` in the light loop)
       uint32_t in_ = 0u, out_ = 0u, str_ = 0u;
+      double gapmin = 1e30;
       for (int k = 0; k < sc.nS && k < MAXS; ++k) {
         const double dx = L[0] - sc.prims[k].a[0], dy = L[1] - sc.prims[k].a[1], dz = L[2] - sc.prims[k].a[2];
         const double l2d = (dx * dx + dy * dy) + dz * dz;
@@ -585,6 +596,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         if (l2 < (r + RL) * (r + RL) * 1.001f) in_ |= 1u << k;
         if (l2 > rin * rin * 0.999f) out_ |= 1u << k;
         if (fabs(sqrt(l2d) - sc.prims[k].a[3]) <= RS * (1.0 + 1e-5 * sc.prims[k].a[3])) str_ |= 1u << k;
+        gapmin = fmin(gapmin, fabs(sqrt(l2d) - sc.prims[k].a[3]));
       }
       for (int k = 0; k < sc.nP && k < MAXP; ++k) {
         const Prim& pl = sc.prims[sc.nS + k];
@@ -601,6 +613,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         if (in_big && !in_small) str_ |= 0x1000000u << k;
       }
       s_lin[li] = in_; s_lout[li] = out_; s_lstr[li] = str_; s_labs[li] = labs;
+      s_lend[li] = (float)fmin(80.0 * fmax(gapmin - 1.001 * (double)RL, 0.0), 1e30);
       {
         const float hx = (float)L[0], hy = (float)L[1], hz = (float)L[2];
         s_lt[li][0] = make_float4(hx, hy, hz, (float)L[8]);
@@ -1138,6 +1151,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // outside it (or is the hit's own) and the light's samples outside it (ls_light_sum_simple); wave-uniform
         const bool simple = OPAQUE && MAXB == 0 && !lo_path && !(RT_DBG(fp) & 64u) && ((act & 0xFFFFu & l_in) == 0u) &&
                             !__any(active & ((bad_cc & act) != 0u));
+        // (sample-end decisions of far hits, see s_lend: only the loops that compare roots with |ts|^2)
+        const bool end_bad = simple ? false : (ocm >= s_lend[li]);
         if (lo_path)
           total = ls_light_sum<MAXS, MAXS, MAXP, MAXB, OPAQUE, true>(pr, act, nB, cells, n_cells, key, cell32, tl, right, up,
                                                                      T0, T1, T2, tol.kap, fl, own);
@@ -1197,7 +1212,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         // far hits: the fp32 position of a segment's far end is off by more than the slack s_lstr was built with
         const bool far = 16.0f * LS_U * tsm > 1e-4f * (1.0f + l_abs);
         // (ls_light_sum_simple counts blocked samples in floats: a sum that is not a whole number had a denormal decision value)
-        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far | (simple & (total != floorf(total)));
+        undecided = !ls_decided(fl, tol) | (T0 < 9.0f * RL * RL) | !(T0 > 1e-12f) | far | end_bad | (simple & (total != floorf(total)));
         if (RT_DBG(fp) & (1u << 23))    // cause bits: 1 grazing discriminant, 2 root at the origin, 4 parallel plane, 8 light close, 16 far
           dbg_cause = ((!(fl.unc < -tol.kap0) && fl.unc < 3.0e38f) ? 1u : 0u) | (fl.unc >= 3.005e38f ? (32u << (int)((fl.unc - 3.005e38f) * 1e-36f)) : 0u) | (!(fl.mlow > __float_as_uint(tol.elo)) ? 2u : 0u) | (!(fl.dmin > tol.eden) ? 4u : 0u) |
                       (((T0 < 9.0f * RL * RL) | !(T0 > 1e-12f)) ? 8u : 0u) | (far ? 16u : 0u);

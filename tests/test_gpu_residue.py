@@ -107,3 +107,43 @@ lgt 0.0 1.5 6.0 0.5 0.5 0.8 1 0.9 0.5
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 11), precision="fp32", verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+def test_far_hit_and_a_light_just_inside_a_sphere(oracle):
+    """tests/golden/residue/random_200792.txt (random_scene_text(200792, opaque=False), inputs only): a point light 0.01 inside
+    a transparent sphere of radius 1.5 and a reflected ray that reaches a plane 434 units away.  Whether the sphere's far
+    root lies before or behind the light is then an fp32 decision with an error of several units of |ts|^2 against a margin
+    of ~2: the fp32 kernels counted the far root as a second crossing (T = 0.25 instead of 0.5: two channels 2 levels off).
+    Both kernels now compare the light's distance from the surface with the pair's own error bound."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", "random_200792.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    W, H = 56, 40
+    ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 200792))
+    img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 200792), precision="fp32", verbose=False)
+    d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+    # the same geometry through k_shade_ls (three spheres, a mirror floor; no surfaces meeting: no marks)
+    text = """cam 0 2 10  0 1 0  0 1 0  1.4 2
+set 0.3 0.4 0.5 1 3
+mtl 0.6 0.6 0.6 0.5 0.5 0.5 0.6 0.6 0.6 0 0.0
+mtl 0.8 0.3 0.2 0.5 0.5 0.5 0.0 0.0 0.0 30 0.5
+mtl 0.2 0.4 0.8 0.5 0.5 0.5 0.3 0.3 0.3 10 0.3
+pln 0 1 0 -1 1
+sph 1.0 2.0 1.0 1.5 2
+sph -3.0 1.0 0.0 1.0 3
+sph 4.0 0.5 -2.0 0.8 2
+lgt 1.0 2.0 2.49 0.9 0.9 0.9 0.6 0.9 0.0
+lgt 1.0 3.51 1.0 0.5 0.6 0.9 0.6 0.9 0.0
+lgt -4 6 2 0.5 0.6 0.9 1 0.7 0.5
+"""
+    cam, st, objs = parse_scene_text(text)
+    mats, surfs, lights = separate_objects(objs)
+    W, H = 160, 90
+    ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 5))
+    img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 5), precision="fp32", verbose=False)
+    d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+    assert d8.max() <= 1, f"hand-made: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
