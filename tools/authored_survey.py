@@ -65,7 +65,7 @@ if __name__ == "__main__":
     for seed in range(FIRST, FIRST + N):
         cam, st, objs = parse_scene_text(authored_scene_text(seed))
         mats, surfs, lights = separate_objects(objs)
-        W, H = 80, 60
+        W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (80, 60)      # tools/authored_survey.py [n [first_seed [W H]]]
         ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed))
         s32 = {}
         img64 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), verbose=False)
