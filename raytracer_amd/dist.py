@@ -61,20 +61,31 @@ def gather_tiles(tile, tiling: RowTiling, rank, *, dst=0, group=None, out=None, 
         if scratch is None:
             scratch = new_scratch(tile, world)
         dist.gather(tile, gather_list=scratch, dst=dst, group=group)
-        if out is None:
-            out = torch.empty((tiling.height, tiling.width) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
-        base = getattr(scratch[0], "_rt_stack", None)
-        perm = getattr(tiling, "_perm", None)
-        if perm is not None and base is not None and base.shape[0] == world * tiling.max_rows:
-            # all tiles live in one allocation: de-interleave the frame with ONE gather kernel
-            torch.index_select(base, 0, perm, out=out)
-            return out
-        for p in range(world):
-            idx = tiling._idx[p] if hasattr(tiling, "_idx") else torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long)
-            out.index_copy_(0, idx, scratch[p][: tiling.n_rows(p)])
-        return out
+        return reassemble(scratch, tiling, out)
     dist.gather(tile, gather_list=None, dst=dst, group=group)
     return None
+
+
+def reassemble(scratch, tiling: RowTiling, out=None):
+    """The gather root's last step: the `world` received tiles (rows beyond a part's own count are padding) -> the frame
+    [H, W, C].  Tiles made by new_scratch() + a tiling prepared by cache_row_indices() take ONE index_select over the
+    stacked tiles; anything else one index_copy_ per part.  (Separate from gather_tiles so that it is testable without
+    a process group: the nccl branch of gather_tiles runs only on a multi-GPU node.)"""
+    import torch
+    world = tiling.world_size
+    tile = scratch[0]
+    if out is None:
+        out = torch.empty((tiling.height, tiling.width) + tuple(tile.shape[2:]), dtype=tile.dtype, device=tile.device)
+    base = getattr(scratch[0], "_rt_stack", None)
+    perm = getattr(tiling, "_perm", None)
+    if perm is not None and base is not None and base.shape[0] == world * tiling.max_rows and perm.device == base.device:
+        # all tiles live in one allocation: de-interleave the frame with ONE gather kernel
+        torch.index_select(base, 0, perm, out=out)
+        return out
+    for p in range(world):
+        idx = tiling._idx[p] if (hasattr(tiling, "_idx") and tiling._idx[p].device == tile.device) else torch.as_tensor(tiling.rows[p], device=tile.device, dtype=torch.long)
+        out.index_copy_(0, idx, scratch[p][: tiling.n_rows(p)])
+    return out
 
 
 def new_scratch(tile, world):

@@ -82,3 +82,28 @@ def test_stacked_tiles_permutation_matches_per_part_copy():
     for p in range(4):
         b.index_copy_(0, t._idx[p], parts[p][: t.n_rows(p)])
     assert torch.equal(a, b) and torch.equal(a[:, 0, 0], torch.arange(37, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("world,H,block_rows", [(2, 50, 8), (3, 22, 4), (8, 2160, 8), (8, 61, 8)])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "uint8"])
+def test_reassemble_stacked_and_separate_tiles(world, H, block_rows, dtype):
+    """The gather root's de-interleave (one index_select over the stacked receive buffers, or one index_copy_ per part)
+    for the tile formats bench.py gathers: float32 / float64 radiance and the 8-bit image (--out-format u8)."""
+    import torch
+    from raytracer_amd.dist import RowTiling, cache_row_indices, new_scratch, reassemble
+    W = 5
+    dt = getattr(torch, dtype)
+    frame = (torch.arange(H * W * 3).reshape(H, W, 3) % 251).to(dt)
+    for cached in (True, False):
+        tiling = RowTiling(H, W, world, block_rows)
+        if cached:
+            cache_row_indices(tiling, "cpu")
+        tile0 = torch.zeros((tiling.max_rows, W, 3), dtype=dt)
+        for stacked in (True, False):
+            scratch = new_scratch(tile0, world) if stacked else [torch.zeros_like(tile0) for _ in range(world)]
+            for p in range(world):
+                scratch[p][: tiling.n_rows(p)] = frame[torch.as_tensor(tiling.rows[p], dtype=torch.long)]
+                scratch[p][tiling.n_rows(p):] = 77                       # padding rows must not reach the frame
+            out = reassemble(scratch, tiling, torch.empty((H, W, 3), dtype=dt))
+            assert torch.equal(out, frame), (cached, stacked)
+            assert torch.equal(reassemble(scratch, tiling), frame)

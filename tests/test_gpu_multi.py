@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import rel_err, scene_path
+from conftest import ROOT, rel_err, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -151,3 +151,51 @@ def test_two_frames_in_flight_give_the_single_frames(oracle, precision):
         a.close(); b2.close()
         for b in bufs:
             hip.hipFree(b)
+
+
+def test_rccl_collectives_of_the_bench_on_a_raw_stream():
+    """bench.py's N > 1 path issues torch.distributed.gather / all_reduce / all_gather / barrier on the nccl (= RCCL) backend
+    with a raw hipStreamNonBlocking stream (torch.cuda.ExternalStream) current, then de-interleaves the received tiles on
+    that stream.  No multi-GPU node is available to the tests, so this runs the same calls in a ONE-rank RCCL group on
+    the one GPU of the box (in a child process: a process group is process-wide state): it cannot show scaling, but it
+    does show that the backend, the external stream and the calls fit together on this stack."""
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        import torch, torch.distributed as dist
+        from bench import new_stream
+        from raytracer_amd.dist import RowTiling, cache_row_indices, gather_tiles, new_scratch
+        torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", device_id=dev)
+        render, comm = new_stream(dev), new_stream(dev)
+        tiling = cache_row_indices(RowTiling(40, 16, 1, 8), dev)
+        for dt in (torch.float32, torch.float64, torch.uint8):
+            with torch.cuda.stream(render):
+                tile = (torch.arange(tiling.max_rows * 16 * 3, device=dev) % 251).reshape(tiling.max_rows, 16, 3).to(dt)
+            ev = torch.cuda.Event(); ev.record(render)
+            scratch = new_scratch(tile, 1)
+            frame = torch.empty((40, 16, 3), dtype=dt, device=dev)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                dist.gather(tile, gather_list=scratch, dst=0)          # (gather_tiles short-cuts a world of one)
+                from raytracer_amd.dist import reassemble
+                reassemble(scratch, tiling, frame)
+            torch.cuda.synchronize()
+            assert torch.equal(frame, tile), dt
+        t = torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        parts = [torch.zeros_like(t)]
+        dist.all_gather(parts, t)
+        assert torch.equal(parts[0], t)
+        dist.barrier(); torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("rccl ok")
+    """)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
