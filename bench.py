@@ -325,7 +325,11 @@ def main():
                  "rows_per_rank": [int(p_[2]) for p_ in per], "tile_rows_gathered": tiling.max_rows,
                  "frames_with_events": len(timed_mine), "pipelined": bool(pipelined), "frames_in_flight": depth,
                  "note": "compute_ms: first kernel start -> last kernel end of a rank's frame (HIP events on its render stream); gather_ms: "
-                         "torch.distributed.gather of the padded tiles + reassembly on the stream it runs on (rank 0 waits for the slowest peer)"}
+                         "torch.distributed.gather of the padded tiles + reassembly on the stream it runs on (rank 0 waits for the slowest peer); "
+                         "with k frames in flight the frames share the GPU: a compute-bound rank then shows compute_ms ~ k x ms_per_step, "
+                         "RT_BENCH_PIPELINE=0 gives the unshared frame time",
+                 "kernel_ms": {"per_rank_note": "sum of the event-timed kernels' own durations of a frame on rank 0 (trace + shade + other)",
+                               "rank0": round(sum(s_.trace_ms + s_.shade_ms + s_.other_ms for s_ in timed_mine) / max(len(timed_mine), 1), 4)}}
 
     verify = None
     if not args.no_verify and world > 1 and rank == 0:

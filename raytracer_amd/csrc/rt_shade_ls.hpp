@@ -859,7 +859,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         near_scene &= fabsf(cc) < 1000.0f * (float)r2_;
         oc2max = fmaxf(oc2max, cc + (float)r2_);
         if (own == k) { own_in_bit = cc < 0.0f ? 1u << k : 0u; own_out_bit = cc < 0.0f ? 0u : 1u << k; }
-        bad_cc |= ((cc < 0.0f) | ((own != k) & (cc < 1e-4f * (float)r2_))) ? 1u << k : 0u;
+        // (on the surface: within 5e-5 r + 5e-6 of it — the absolute part covers the reference's 2e-6 bound for small spheres)
+        bad_cc |= ((cc < 0.0f) | ((own != k) & (cc < fmaf(1e-4f, (float)r2_, 1e-5f * (float)s_.a[3])))) ? 1u << k : 0u;
         a_tauS[k] = 0.0f; if (!OPAQUE) a_tauS[k] = (float)s_matd[s_.mat][10];
       }
     }
@@ -1039,6 +1040,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             }
         }
         lane_full &= !own_light_inside;
+        // No umbra claim either when the shadow origin lies on a FOREIGN sphere's surface (bad_cc) while some sample of the
+        // light may be inside that sphere: the entry crossing is then closer than the reference's 2e-6 bound and not seen,
+        // and the exit lies beyond the sample — the segment is NOT blocked although the whole fan enters the sphere.  (A plane
+        // hit next to the circle where the plane leaves a sphere with the light partly inside: scaled scene 900389, one
+        // pixel 3 levels off.  The lane then reaches the sample loop, which leaves roots at the origin to fp64.)
+        lane_full &= (bad_cc & l_in & 0xFFFFu) == 0u;
         float4 pn4[MAXP > 0 ? MAXP : 1];
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) pn4[k] = s_plnf[k];

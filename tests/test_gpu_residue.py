@@ -147,3 +147,23 @@ lgt -4 6 2 0.5 0.6 0.9 1 0.7 0.5
     img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 5), precision="fp32", verbose=False)
     d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
     assert d8.max() <= 1, f"hand-made: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+def test_umbra_claim_with_an_unseen_entry_crossing(oracle):
+    """tests/golden/residue/scaled_900389.txt (tools/scaled_survey.py: random_scene_text(1000 + 900389, opaque) with every
+    length x 0.01, inputs only): a plane hit 1.6e-6 outside the sphere the plane cuts, and a light whose sample square lies
+    partly inside that sphere.  The whole shadow fan enters the sphere — but within 2e-6 of the origin, which the reference
+    does not see (ray_tracer.py:279-291: origin shifted 1e-6, hits accepted beyond another 1e-6), and for the samples inside
+    the sphere the exit lies beyond the sample: 3 of 9 samples are lit.  k_shade_ls claimed an umbra (one pixel 3 levels
+    off); the claim is now withheld when the origin lies on a foreign sphere's surface and the light may be inside it."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", "scaled_900389.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    for (W, H) in ((56, 40), (112, 80)):
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 900389))
+        img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 900389), precision="fp32", verbose=False)
+        d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+        assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
