@@ -874,10 +874,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
         const Prim& s_ = P[nS + k];
         a_D2n[k].y = (float)(s_.a[3] - ((p.x * s_.a[0] + p.y * s_.a[1]) + p.z * s_.a[2]));
         a_tauP[k] = 0.0f; if (!OPAQUE) a_tauP[k] = (float)s_matd[s_.mat][10];
-        // A plane through the shadow origin within rounding (a floor hit on the line where the floor meets a wall; the hit's
-        // own plane is 1e-6 away): its root is +-1e-16, which the reference does not see (t > 1e-6) but whose sign decides
-        // ls_light_sum_simple's test num*den > 0.  Such lanes take ls_light_sum, which leaves a root at the origin to fp64.
-        bad_cc |= fabsf(a_D2n[k].y) < 0.5e-6f ? 0x10000u << k : 0u;
+        // A FOREIGN plane within 6e-6 of the shadow origin (a floor hit on or next to the line where the floor meets a wall;
+        // two nearly parallel planes; the hit's own plane, 1e-6 away, has the slow path LO): its crossing can lie within the
+        // reference's 2e-6 bound along the ray (t' = |num| / |N.d| >= |num|) and is then not seen, while
+        // ls_light_sum_simple's test 0 < num / den has no lower bound.  Such lanes take ls_light_sum, which leaves roots
+        // within ~4e-6 of the origin to fp64.  (Scaled scene 1300544: two planes 2e-6 apart at the hit, 43 levels off.)
+        bad_cc |= ((own != nS + k) & (fabsf(a_D2n[k].y) < 6e-6f)) ? 0x10000u << k : 0u;
       }
     }
 #pragma unroll

@@ -167,3 +167,23 @@ def test_umbra_claim_with_an_unseen_entry_crossing(oracle):
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 900389), precision="fp32", verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+def test_foreign_plane_within_the_two_micron_bound(oracle):
+    """tests/golden/residue/scaled_1300544.txt (random_scene_text(1300544, opaque=False) with every length x 0.001, inputs
+    only): two nearly parallel opaque planes a few 1e-6 apart where a reflected ray hits one of them.  The shadow ray's
+    crossing of the OTHER plane lies within 2e-6 of the origin, which the reference does not see (ray_tracer.py:279-291);
+    the square-root-free loop's plane test 0 < num / den < 1 has no lower bound and shaded the pixel as blocked for two
+    lights (43 levels off).  Lanes with a foreign plane within 6e-6 of the shadow origin now take the loop that leaves
+    roots at the origin to fp64."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", "scaled_1300544.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    for (W, H) in ((56, 40), (112, 80)):
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1300544))
+        img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1300544), precision="fp32", verbose=False)
+        d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+        assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
