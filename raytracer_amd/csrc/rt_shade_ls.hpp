@@ -279,6 +279,7 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
         const v2f tsy = pk_fma(oj, splat(up.y), pk_fma(oi, splat(right.y), splat(tl.y)));
         const v2f tsz = pk_fma(oj, splat(up.z), pk_fma(oi, splat(right.z), splat(tl.z)));
         const v2f ix = pk_rcp(tsx), iy = pk_rcp(tsy), iz = pk_rcp(tsz);
+        const float chord_lim = 6.75e-6f * raw_rsq(T0);
         // a direction component within 1e-3 of parallel to a slab: its 1/x carries the rounding of ts (up to
         // ~1e-3 relative here) -> not decided in fp32
         {
@@ -303,7 +304,10 @@ __device__ __forceinline__ float ls_light_sum(LsPrims<MAXS, MAXP, MAXB, OPAQUE>&
               // above), or a slab root lies at the sample itself (tau = 1): not decided in fp32
               // (only where it can matter: a degenerate interval [tn, tf] that overlaps the segment's (0, 1), a sample-end
               // root of a box that is not clearly missed — a box whose slab roots all lie beyond the light needs no decision)
-              const float g0 = 4e-3f * (fabsf(tn.x) + fabsf(tf.x)), g1 = 4e-3f * (fabsf(tn.y) + fabsf(tf.y));
+              // (+ a chord shorter than ~4e-6 along the ray, whatever its relative size: the reference's walk steps 2e-6 from
+              // one crossing to the next and sees such a chord as ONE crossing or none — a ray clipping a box edge right at
+              // the hit, scaled scene 1400877.  tau = distance / |ts| and |ts| >= 2/3 |tl| here: 4.5e-6 / |ts| <= chord_lim)
+              const float g0 = 4e-3f * (fabsf(tn.x) + fabsf(tf.x)) + chord_lim, g1 = 4e-3f * (fabsf(tn.y) + fabsf(tf.y)) + chord_lim;
               const bool graze0 = (fabsf(tf.x - tn.x) <= g0) & (fminf(tn.x, tf.x) < 1.004f) & (fmaxf(tn.x, tf.x) > -4e-3f);
               const bool graze1 = (fabsf(tf.y - tn.y) <= g1) & (fminf(tn.y, tf.y) < 1.004f) & (fmaxf(tn.y, tf.y) > -4e-3f);
               const bool end0 = (tf.x - tn.x >= -g0) & ((fabsf(tn.x - 1.0f) <= 4e-3f) | (fabsf(tf.x - 1.0f) <= 4e-3f));
@@ -1152,7 +1156,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LS_WAVES)
             }
           }
         }
-        tol.kap0 = 2.0f * e_b * e_b;
+        // (+ (2.2e-6 |ts|)^2: a chord shorter than ~4.4e-6 along the ray — two crossings the reference's walk sees as one —
+        // is a discriminant below that, whatever the scene's size; it only exceeds the rounding part for scenes < 1e-3)
+        tol.kap0 = fmaf(4.84e-12f * tsm, tsm, 2.0f * e_b * e_b);
         tol.elo = 2.0f * T_LO * tsm + 2.0f * (e_b + tol.kap);
         tol.eden = 12.0f * LS_U * tsm;
         LsFlags fl = ls_flags_init();

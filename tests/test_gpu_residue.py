@@ -187,3 +187,24 @@ def test_foreign_plane_within_the_two_micron_bound(oracle):
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1300544), precision="fp32", verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+def test_chord_through_a_box_edge_shorter_than_the_walk_step(oracle):
+    """tests/golden/residue/scaled_1400877.txt (random_scene_text(1400877, opaque=False) with every length x 0.005, inputs
+    only): a hit on the top face of a transparent box 1.2e-5 from its edge, and a light slightly below that face: the
+    shadow ray re-enters the box 1.5e-5 from the origin and leaves it through the side face 2e-6 later.  The reference's
+    walk steps 2e-6 from one crossing to the next (ray_tracer.py:279-291) and counts such a chord once or not at all;
+    k_shade_ls's box test only flagged chords that are short RELATIVE to their distance (9 levels off).  Chords shorter
+    than ~4.5e-6 along the ray are now left to the exact walk whatever their relative size (spheres: the same bound on
+    the discriminant)."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", "scaled_1400877.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    for (W, H) in ((56, 40), (112, 80)):
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1400877))
+        img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1400877), precision="fp32", verbose=False)
+        d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+        assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
