@@ -86,7 +86,7 @@ __device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, 
     if (fabsf(den) > 2.0f * U8) {
       const float t = num * raw_rcp(den);
       r.t0 = t; r.e0 = fabsf(t) * (1.5f * U8 * raw_rcp(fabsf(den)) + 4.0f * U1);
-    } else { r.t0 = 1.0f; r.e0 = 3.0e38f; }               // parallel within rounding: nothing is known about the root
+    } else { r.t0 = 1e-30f; r.e0 = 3.0e38f; }             // parallel within rounding: nothing is known about the root (t0: any value inside (0, segment length), see pair_close)
   } else {
     const float jx = raw_rcp(dx), jy = raw_rcp(dy), jz = raw_rcp(dz);
     const float ax = (float)(s_.a[0] - p.x) * jx, bx = (float)(s_.a[3] - p.x) * jx;
@@ -96,7 +96,10 @@ __device__ __forceinline__ PairRoots pair_roots(const Prim& s_, d3 p, float dx, 
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const float jm = fmaxf(fmaxf(fabsf(jx), fabsf(jy)), fabsf(jz));
     const float rel = 2.0f * fmaf(U8, jm, 4.0f * U1);
-    if (jm > 1e3f) { r.t0 = 1.0f; r.e0 = 3.0e38f; }        // a component nearly parallel to a slab: nothing is known about the roots -> "close to everything"
+    // a component nearly parallel to a slab: nothing is known about the roots -> "close to everything".  (The stand-in root must
+    // lie inside (0, segment length) for pair_close to look at it: it used to be 1.0, beyond any light closer than one unit —
+    // scaled scene 1501416: a box's exit and a sphere's crossing 2e-7 apart on such a segment counted twice, 5 levels off)
+    if (jm > 1e3f) { r.t0 = 1e-30f; r.e0 = 3.0e38f; }
     else if (tn <= tf + rel * (fabsf(tn) + fabsf(tf))) {
       r.t0 = tn; r.e0 = rel * fabsf(tn);
       r.t1 = tf; r.e1 = rel * fabsf(tf);

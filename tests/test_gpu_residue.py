@@ -208,3 +208,23 @@ def test_chord_through_a_box_edge_shorter_than_the_walk_step(oracle):
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1400877), precision="fp32", verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+def test_merged_crossings_on_a_segment_nearly_parallel_to_a_slab(oracle):
+    """tests/golden/residue/scaled_1501416.txt (random_scene_text(1501416, opaque=False) with every length x 0.001, inputs
+    only; 19 surfaces: k_shade_fast): a shadow segment whose x component is 2.6e-4 of its length leaves a transparent box
+    2e-7 before it crosses a transparent sphere — one crossing for the reference's walk.  k_shade_fast knows nothing about
+    the slab roots of such a segment and marks them "close to everything" with a stand-in root — which was 1.0, beyond
+    the light (0.0085 away), so pair_close never looked at it: 5 levels off.  Independent of the scene's size: any light
+    closer than one unit."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", "scaled_1501416.txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    for (W, H) in ((56, 40), (112, 80)):
+        ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1501416))
+        img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1501416), precision="fp32", verbose=False)
+        d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+        assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
