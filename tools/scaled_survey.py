@@ -2,7 +2,7 @@
 """The randomised test scenes with every length multiplied by a factor (0.01 ... 1000): the reference's epsilons are
 absolute (1e-6 origin shift, t > 1e-6), the fp32 kernels' bounds mostly relative — scenes far from unit size find the
 bounds that are neither.  fp32 against the oracle (<= 1 level) and fp64 against the oracle (<= 1e-9).
-    python tools/scaled_survey.py [n_seeds [first_seed [random|authored|many]]]
+    python tools/scaled_survey.py [n_seeds [first_seed [random|authored|many|settings]]]
 (authored: the grid-aligned scenes of tools/authored_survey.py — at factors that are not powers of two their exact
 coincidences become coincidences within a few ulp.)"""
 import os, sys
@@ -12,6 +12,7 @@ from test_gpu_random_scenes import random_scene_text
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from authored_survey import authored_scene_text
 from test_gpu_many_spheres import many_spheres_text
+from settings_survey import varied_text
 from raytracer_amd import parse_scene_text, separate_objects
 from raytracer_amd.render import render_hip
 from raytracer_amd.image import quantize_u8
@@ -46,14 +47,15 @@ def scaled(text, s):
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 KIND = sys.argv[3] if len(sys.argv) > 3 else "random"
-W, H = (56, 40) if KIND == "random" else ((80, 60) if KIND == "authored" else (72, 48))
+W, H = {"random": (56, 40), "authored": (80, 60), "many": (72, 48)}.get(KIND, (48, 36))
 bad = 0; worst = 0; worst64 = 0.0
 SCALES = tuple(float(x) for x in os.environ["SCALES"].split(",")) if os.environ.get("SCALES") else (0.01, 0.1, 10.0, 100.0, 1000.0)
 for s in SCALES:
     for opaque in ((True, False) if KIND == "random" else (None,)):
         for seed in range(FIRST, FIRST + N):
             base = (random_scene_text(1000 * int(opaque) + seed, opaque) if KIND == "random" else authored_scene_text(seed) if KIND == "authored"
-                    else many_spheres_text(7 + seed % 10, 5000 + seed, seed % 2 == 1))      # "many": the 7-16 sphere scenes
+                    else many_spheres_text(7 + seed % 10, 5000 + seed, seed % 2 == 1) if KIND == "many"      # the 7-16 sphere scenes
+                    else varied_text(seed))      # "settings": large shadow grids, deep recursion, many lights / planes, large scenes
             text = scaled(base, s)
             cam, st, objs = parse_scene_text(text)
             mats, surfs, lights = separate_objects(objs)
