@@ -321,6 +321,12 @@ struct rt_scene {
   bool all_opaque = true;
   int n_coincident = 0;    // primitives marked by mark_coincident (scenes with transparency)
   int shade_variant = 0;   // RT_SHADE=ls|general: first fp32 shade kernel tried (A/B testing)
+  // A used material with shininess 0: in the sequential renderer its specular term is a STEP at r.v = 0 (added only for
+  // r.v > 0, where it is 1: ray_tracer.py:356-359).  k_shade_ls forms the Phong light direction from the offset point p
+  // (1e-6 from the hit point), an error of 1e-6 / |tl| in r.v that decides the step for |r.v| below it (scaled_survey.py
+  // SEQ=1: 9 of 6,500 scenes at scale 0.002 off by up to 84 levels); k_shade_fast forms it from the hit point itself, so
+  // sequential fp32 frames of such scenes go there.
+  bool any_shin0 = false;
   // workspace
   size_t cap_pixels = 0, cap_queue = 0, cap_hits = 0, cap_out = 0;
   size_t min_queue = 0;          // queue capacity requested after an overflow (rays per level)
@@ -700,6 +706,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   s->all_opaque = true;
   for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 10] != 0.0) s->all_opaque = false;
   s->ds.all_opaque = s->all_opaque ? 1 : 0;
+  for (const Prim& p : prims) if (mats[(size_t)p.mat * MAT_STRIDE + 9] == 0.0) s->any_shin0 = true;
   s->ds.scene_m = 0.0f;       // L1 size of the hierarchy's bounds: scales the fp32 slack of k_shade_fast's node tests
   for (int k = 0; k < 3; ++k) s->ds.scene_m += std::max(std::fabs(accel_lo[k]), std::fabs(accel_hi[k]));
   if (const char* e = getenv("RT_SHADE")) s->shade_variant = e[0] == 'g' ? 2 : 0;
@@ -1048,7 +1055,8 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
   // k_shade_ls, `fused`), no k_trace launch and no hit list for the 75 % of a frame's hits that are camera-ray hits.
   // RT_FUSE0=0 keeps the two-kernel level 0 (A/B).
   FrameParams fp = fp_in;
-  const bool ls_kernel = fr->precision == RT_FP32 && lds && s->shade_variant == 0 && s->n_coincident == 0 && shade_ls_serves(s->ds, fp);
+  const bool ls_allowed = s->shade_variant == 0 && s->n_coincident == 0 && !(fp.sequential && s->any_shin0);
+  const bool ls_kernel = fr->precision == RT_FP32 && lds && ls_allowed && shade_ls_serves(s->ds, fp);
   // (fp64 frames of LDS-resident scenes: k_shade_exact_items fuses its level 0 the same way)
   const bool items_kernel = fr->precision == RT_FP64 && lds && (fp.n_shadow > 1 ? fp.n_shadow * fp.n_shadow : 1) <= ITEM_CHUNK &&
                             !(getenv("RT_EXACT_ITEMS") && atoi(getenv("RT_EXACT_ITEMS")) == 0);
@@ -1103,7 +1111,7 @@ static int launch_frame(rt_scene* s, const WorkBufs& wb, const DevCamera& cam, c
       } else {
         // small scenes: register-cached per-hit primitive terms; otherwise the general kernel
         bool done = false;
-        if (s->shade_variant == 0 && s->n_coincident == 0) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->num_cu, s->stream);
+        if (ls_allowed) done = launch_shade_ls(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->num_cu, s->stream);
         if (!done)
           launch_shade_fast(s->ds, s->all_opaque, cam, fp, level, cur, nxt, level_hits, wb.counters, (float*)fb, wb.fix, sgrid, s->num_cu, s->stream);
       }

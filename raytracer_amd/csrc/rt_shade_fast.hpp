@@ -116,6 +116,20 @@ __device__ __forceinline__ bool pair_close(const PairRoots& a, const PairRoots& 
   return one(a.t0, a.e0, b.t0, b.e0) | one(a.t0, a.e0, b.t1, b.e1) | one(a.t1, a.e1, b.t0, b.e0) | one(a.t1, a.e1, b.t1, b.e1);
 }
 
+// r.v > 0 of the sequential renderer's specular term, formed like phong_light_exact does (rt_kernels.hpp) from the exact hit
+// geometry.
+__device__ __forceinline__ bool seq_specular_step(d3 o, d3 hp, d3 n, double lx, double ly, double lz) {
+  d3 vd = mk3(o.x - hp.x, o.y - hp.y, o.z - hp.z);
+  double vn = norm3(vd); if (vn < EPS) vn = 1.0;                  // normalize, ray_tracer.py:17-21: shorter than EPS stays as it is
+  vd = mk3(vd.x / vn, vd.y / vn, vd.z / vn);
+  const d3 tld = mk3(lx - hp.x, ly - hp.y, lz - hp.z);
+  double ln = norm3(tld); if (ln < EPS) ln = 1.0;
+  const d3 mld = mk3(-(tld.x / ln), -(tld.y / ln), -(tld.z / ln));
+  const double dnd = dot3(mld, n);
+  const d3 rfd = mk3(mld.x - (2 * dnd) * n.x, mld.y - (2 * dnd) * n.y, mld.z - (2 * dnd) * n.z);
+  return dot3(rfd, vd) > 0;
+}
+
 template <int CH, bool OPAQUE, bool HAS_BOX, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCENE && CH <= 9) ? 2 : 1))) void k_shade_fast(DevScene sc, DevCamera cam, FrameParams fp, int level, RayQueue q,
                                                       RayQueue nq, const HitRec* __restrict__ hits, Counters* C,
@@ -822,8 +836,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!LDS_SCE
         dif[2] = fmaf((float)mat[2] * (float)lg[5], s1, dif[2]);
         const float dn = -dotf(l, nf);                                                    // (-l).n
         const f3 rf = mkf(fmaf(-2.0f * dn, nf.x, -l.x), fmaf(-2.0f * dn, nf.y, -l.y), fmaf(-2.0f * dn, nf.z, -l.z));
-        const float rdv = fmaxf(dotf(rf, v), 0.0f);
+        float rdv = fmaxf(dotf(rf, v), 0.0f);
         const float shin = (float)mat[9];
+        // Sequential renderer, shininess 0: the specular term is a STEP at r.v = 0 (1 for r.v > 0, absent otherwise,
+        // ray_tracer.py:356-359).  Grid-aligned scenes put r.v at zero up to the rounding of the reference's own fp64
+        // arithmetic, which only the literal fp64 evaluation reproduces: within 1e-4 of the step it is formed like
+        // phong_light_exact does (rare, wave-uniform).
+        // (LDS-staged scenes only: their instantiations run one wave per SIMD and have the registers; in the large-scene
+        // kernel the fp64 code cost 26 more spilled VGPRs — there the step stays an fp32 decision)
+        if (LDS_SCENE && fp.sequential && __any((shin == 0.0f) & (fabsf(dotf(rf, v)) < 1e-4f))) {
+          if ((shin == 0.0f) & (fabsf(dotf(rf, v)) < 1e-4f))
+            rdv = seq_specular_step(r.o, hp, n, lg[0], lg[1], lg[2]) ? fmaxf(rdv, 1e-30f) : 0.0f;
+        }
         // np.power(0, 0) == 1; the sequential renderer adds the specular term only for r.v > 0 (ray_tracer.py:356-359)
         // (rdv ** shininess as exp2(shininess * log2(rdv)) on the raw hardware transcendentals, as in k_shade_ls: 1 ulp each,
         // relative error <= shininess * 2^-22 — far inside the 8-bit tolerance; powf() is ~70 instructions per (hit, light))

@@ -228,3 +228,26 @@ def test_merged_crossings_on_a_segment_nearly_parallel_to_a_slab(oracle):
         img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", 1501416), precision="fp32", verbose=False)
         d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
         assert d8.max() <= 1, f"{W}x{H}: {(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+
+
+@pytest.mark.parametrize("name,seed,size", [("seq_scaled_2000170", 2000170, (56, 40)), ("seq_scaled_authored_2000368", 2000368, (80, 60))])
+def test_sequential_specular_step_of_shininess_zero(oracle, name, seed, size):
+    """The sequential renderer adds the specular term only for r.v > 0 (ray_tracer.py:356-359); with shininess 0 that is a
+    STEP of height ks at r.v = 0.  tests/golden/residue/seq_scaled_2000170.txt (random scene x 0.002): r.v = 4e-5 on one
+    pixel, and k_shade_ls's Phong light direction (formed from the offset point, 1e-6 / |tl| = 7e-5 off) put it below
+    zero: 59 levels.  seq_scaled_authored_2000368.txt (grid-aligned scene x 50): r.v is zero up to the rounding of the
+    reference's own fp64 arithmetic.  Sequential fp32 frames of scenes with a shininess-0 material now go through
+    k_shade_fast, which forms the direction from the hit point and decides the step in fp64 within 1e-4 of it."""
+    from raytracer_amd import parse_scene_text, separate_objects
+    from raytracer_amd.image import quantize_u8
+    from raytracer_amd.render import render_hip
+    with open(os.path.join(GOLDEN, "residue", name + ".txt")) as f:
+        cam, st, objs = parse_scene_text(f.read())
+    mats, surfs, lights = separate_objects(objs)
+    W, H = size
+    ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), sequential=True)
+    img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False, sequential=True)
+    d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
+    assert d8.max() <= 1, f"{(d8 > 1).sum()} channels off by more than one level (max {d8.max()})"
+    i64 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp64", verbose=False, sequential=True)
+    assert (np.abs(i64 - ref) / np.maximum(np.abs(ref), 1e-12)).max() < 1e-9

@@ -47,6 +47,7 @@ def scaled(text, s):
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 KIND = sys.argv[3] if len(sys.argv) > 3 else "random"
+SEQ = os.environ.get("SEQ") == "1"       # SEQ=1: the sequential renderer's semantics (RT_FLAG_SEQUENTIAL)
 W, H = {"random": (56, 40), "authored": (80, 60), "many": (72, 48)}.get(KIND, (48, 36))
 bad = 0; worst = 0; worst64 = 0.0
 SCALES = tuple(float(x) for x in os.environ["SCALES"].split(",")) if os.environ.get("SCALES") else (0.01, 0.1, 10.0, 100.0, 1000.0)
@@ -59,9 +60,9 @@ for s in SCALES:
             text = scaled(base, s)
             cam, st, objs = parse_scene_text(text)
             mats, surfs, lights = separate_objects(objs)
-            ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed))
-            img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False)
-            i64 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp64", verbose=False)
+            ref = oracle.render(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), sequential=SEQ)
+            img = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp32", verbose=False, sequential=SEQ)
+            i64 = render_hip(cam, st, mats, surfs, lights, W, H, jitter=("pixel", seed), precision="fp64", verbose=False, sequential=SEQ)
             d8 = np.abs(quantize_u8(img).astype(int) - quantize_u8(ref).astype(int))
             e64 = float((np.abs(i64 - ref) / np.maximum(np.abs(ref), 1e-3)).max())
             worst = max(worst, int(d8.max())); worst64 = max(worst64, e64)
